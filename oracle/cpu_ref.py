@@ -1,0 +1,165 @@
+"""ctypes front-end for the CPU oracle (oracle/cpu_ref.c) and, when it has been built in
+this container, the compiled reference itself (oracle/_ref/libref.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (fluid_simulation_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# field selectors shared by cpu_ref.c, ref_harness.cpp and include/fluidsim.h
+DENS, VX, VY, VZ, OBS, P, DIV, VX0, VY0, VZ0, BUF = range(11)
+FIELD_NAMES = ["dens", "v_x", "v_y", "v_z", "obs", "pressure", "divergence",
+               "v_x_prev", "v_y_prev", "v_z_prev", "buffer"]
+GS_LEX, JACOBI = 0, 1
+
+
+def build(force=False):
+    """Compile the oracle (and the reference shim if /root/reference is present)."""
+    need = force or not all(os.path.exists(os.path.join(HERE, n)) for n in ("libcpu_ref.so", "libcpu_ref64.so"))
+    ref_missing = os.path.exists("/root/reference/simulation.cpp") and not os.path.exists(
+        os.path.join(HERE, "_ref", "libref.so"))
+    if need or ref_missing:
+        subprocess.check_call(["make", "-C", HERE] + (["-B"] if force else []),
+                              stdout=subprocess.DEVNULL)
+
+
+def _load(name):
+    path = os.path.join(HERE, name)
+    if not os.path.exists(path):
+        build()
+    return C.CDLL(path)
+
+
+class _Sim:
+    """Common shape of both back-ends: create / mutate / step / read back."""
+    prefix = None
+    dtype = np.float32
+
+    def __init__(self, lib, w, h, d, iter=1, speed=30, dt=0.05, diff=2.0e-5, visc=1.5e-5, acc=15):
+        self.lib = lib
+        self.W, self.H, self.D = w, h, d
+        self.shape = (d + 2, h + 2, w + 2)          # C-order view of x-fastest padded arrays
+        self.n = (w + 2) * (h + 2) * (d + 2)
+        fn = getattr(lib, self.prefix + "create")
+        fn.restype = C.c_void_p
+        fn.argtypes = [C.c_int] * 5 + [C.c_float] * 3 + [C.c_int]
+        self.h = C.c_void_p(fn(w, h, d, iter, speed, dt, diff, visc, acc))
+        if not self.h:
+            raise MemoryError("oracle create failed")
+
+    def _call(self, name, *args, restype=None):
+        fn = getattr(self.lib, self.prefix + name)
+        fn.restype = restype
+        return fn(self.h, *args)
+
+    def close(self):
+        if self.h:
+            self._call("destroy")
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_obstacle(self, x, y, z):
+        self._call("add_obstacle", C.c_int(x), C.c_int(y), C.c_int(z))
+
+    def add_density(self, x, y, z, a):
+        self._call("add_density", C.c_int(x), C.c_int(y), C.c_int(z), C.c_float(a))
+
+    def set_velocity(self, x, y, z, ax, ay, az):
+        self._call("set_velocity", C.c_int(x), C.c_int(y), C.c_int(z), C.c_float(ax), C.c_float(ay), C.c_float(az))
+
+    def get(self, which):
+        out = np.empty(self.n, dtype=self.dtype)
+        rc = self._call("get_field", C.c_int(which), out.ctypes.data_as(C.c_void_p), restype=C.c_int)
+        assert rc == 0
+        return out.reshape(self.shape)
+
+    def set(self, which, arr):
+        a = np.ascontiguousarray(arr, dtype=self.dtype).reshape(-1)
+        assert a.size == self.n
+        rc = self._call("set_field", C.c_int(which), a.ctypes.data_as(C.c_void_p), restype=C.c_int)
+        assert rc == 0
+
+    def set_mask(self, mask):
+        """mask: bool/0-1 array of padded shape (D+2,H+2,W+2); only interior cells may be set."""
+        self.set(OBS, np.asarray(mask, dtype=self.dtype))
+
+    def step_only(self):
+        self._call("step_only")
+
+    def run_one(self):
+        self._call("run_one")
+
+    def diffuse(self, b, field, prev):
+        self._call("diffuse", C.c_int(b), C.c_int(field), C.c_int(prev))
+
+    def project(self):
+        self._call("project")
+
+    def advect(self, b, field, prev):
+        self._call("advect", C.c_int(b), C.c_int(field), C.c_int(prev))
+
+    def set_bounds(self, b, field):
+        self._call("set_bounds", C.c_int(b), C.c_int(field))
+
+    def linear_solver(self, b, field, prev, a, c):
+        self._call("linear_solver", C.c_int(b), C.c_int(field), C.c_int(prev), C.c_float(a), C.c_float(c))
+
+
+class Oracle(_Sim):
+    """The C restatement.  solver = GS_LEX (reference order) or JACOBI."""
+    prefix = "cr_"
+
+    def __init__(self, w, h, d, solver=GS_LEX, fp64=False, threads=None, **kw):
+        lib = _load("libcpu_ref64.so" if fp64 else "libcpu_ref.so")
+        self.dtype = np.float64 if fp64 else np.float32
+        super().__init__(lib, w, h, d, **kw)
+        self._call("set_solver", C.c_int(solver))
+        if threads is not None:
+            lib.cr_set_threads(C.c_int(threads))
+
+    def load_stl(self, path, scale=0.8, rot=(0.0, 0.0, 0.0), translate=(0.0, 0.0, 0.0), seed=1):
+        return self._call("load_stl", C.c_char_p(os.fsencode(path)), C.c_float(scale),
+                          C.c_float(rot[0]), C.c_float(rot[1]), C.c_float(rot[2]),
+                          C.c_float(translate[0]), C.c_float(translate[1]), C.c_float(translate[2]),
+                          C.c_uint(seed), restype=C.c_long)
+
+    def dump_frame(self, directory, append=True):
+        rc = self._call("dump_frame", C.c_char_p(os.fsencode(directory)), C.c_int(1 if append else 0), restype=C.c_int)
+        if rc:
+            raise OSError("dump_frame failed rc=%d" % rc)
+
+
+def have_reference():
+    return os.path.exists(os.path.join(HERE, "_ref", "libref.so"))
+
+
+class Reference(_Sim):
+    """The compiled, unmodified reference (only meaningful at OMP_NUM_THREADS=1)."""
+    prefix = "ref_"
+
+    def __init__(self, w, h, d, **kw):
+        super().__init__(C.CDLL(os.path.join(HERE, "_ref", "libref.so")), w, h, d, **kw)
+
+    def load_stl(self, path, scale=0.8, rot=(0.0, 0.0, 0.0), translate=(0.0, 0.0, 0.0)):
+        self._call("load_stl", C.c_char_p(os.fsencode(path)), C.c_float(scale),
+                   C.c_float(rot[0]), C.c_float(rot[1]), C.c_float(rot[2]),
+                   C.c_float(translate[0]), C.c_float(translate[1]), C.c_float(translate[2]))
+
+    def thread_seed(self):
+        fn = self.lib.ref_thread_seed
+        fn.restype = C.c_uint
+        return int(fn())
+
+    def run(self):
+        self._call("run")
