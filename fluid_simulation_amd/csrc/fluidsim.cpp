@@ -1,0 +1,991 @@
+// fluidsim.cpp -- C-ABI host driver of libfluidsim.so (include/fluidsim.h).
+//
+// Owns device storage, orders the kernels of one time step on a HIP stream, converts
+// between the device layout and the reference's dump layout, and (multi-GPU) exchanges
+// z-slab halo planes over RCCL.  No arithmetic on field data happens on the host and
+// there is no CPU fallback: without a usable HIP device fs_create fails.
+//
+// Orchestration follows Simulation::step()/run() of the reference (simulation.cpp:49-150);
+// every numeric expression lives in kernels.hip.
+#include "../../include/fluidsim.h"
+#include "kernels.h"
+#include "voxelize.h"
+#include "comm.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(FS_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+enum Family { FAM_SWEEP = 0, FAM_DIV, FAM_GRAD, FAM_ADVECT, FAM_BOUNDS, FAM_MISC, FAM_COMM, FAM_COUNT };
+const char* const kFamilyNames[FAM_COUNT] = { "sweep", "divergence", "gradient", "advect", "bounds", "misc", "comm" };
+
+constexpr int NPOOL = FS_NFIELDS + 3;   // named fields + ping-pong scratch
+
+struct Span {
+    hipEvent_t a, b;
+    int fam;
+    long launches;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+struct EngineBase {
+    virtual ~EngineBase() {}
+    virtual int step() = 0;
+    virtual int run_one() = 0;
+    virtual int set_bounds(int b, int field) = 0;
+    virtual int linear_solver(int b, int field, int prev, float a, float c) = 0;
+    virtual int diffuse(int b, int field, int prev) = 0;
+    virtual int project() = 0;
+    virtual int advect(int b, int field, int prev) = 0;
+    virtual int get_field(int which, void* dst, size_t n, int elem) = 0;
+    virtual int set_field(int which, const void* src, size_t n, int elem) = 0;
+    virtual int set_mask(const uint8_t* mask, size_t n) = 0;
+    virtual int point(int which, int x, int y, int z, float v, int set_instead) = 0;
+    virtual int stats(int which, double* out3) = 0;
+    virtual int dump_frame() = 0;
+    virtual int time_sweeps(int b, int field, int prev, float a, float c, int reps, double* ms) = 0;
+    virtual int apply_solid_cells(const int* cells, long n) = 0;
+};
+
+struct fs_sim {
+    // Simulation's public members (simulation.h:44-54); W/H/D are the GLOBAL extents
+    int W = 0, H = 0, D = 0, iter = 0, speed = 0, acc = 0;
+    float dt = 0, diff = 0, visc = 0;
+    // options
+    bool fp64 = false;
+    int solver = FS_SOLVER_JACOBI;
+    std::string dump_dir = "data";
+    int dump_every = 1;
+    unsigned voxel_seed = 1;
+    bool quiet = false, profile = false, elide_dead = false;
+    // device
+    int device = 0;
+    hipStream_t stream = nullptr;
+    EngineBase* eng = nullptr;
+    // z-slab partition (comm.h)
+    fs::Comm comm;
+    // timing
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    double fam_ms[FAM_COUNT] = {0};
+    long fam_launches[FAM_COUNT] = {0};
+    // dumps
+    FILE* dump_fp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool dump_open = false, dump_warned = false, in_run = false;
+    long step_no = 0;
+    long dump_frames = 0;
+
+    int span_begin(int fam)
+    {
+        if (!profile) return -1;
+        Span sp;
+        sp.fam = fam;
+        sp.launches = 0;
+        for (hipEvent_t* ev : { &sp.a, &sp.b }) {
+            if (!event_pool.empty()) { *ev = event_pool.back(); event_pool.pop_back(); }
+            else if (hipEventCreate(ev) != hipSuccess) return -1;
+        }
+        hipEventRecord(sp.a, stream);
+        spans.push_back(sp);
+        return (int)spans.size() - 1;
+    }
+    void span_end(int id, long launches)
+    {
+        if (id < 0) return;
+        spans[id].launches = launches;
+        hipEventRecord(spans[id].b, stream);
+    }
+    void resolve_spans()
+    {
+        if (spans.empty()) return;
+        hipStreamSynchronize(stream);
+        for (Span& sp : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+                fam_ms[sp.fam] += ms;
+                fam_launches[sp.fam] += sp.launches;
+            }
+            event_pool.push_back(sp.a);
+            event_pool.push_back(sp.b);
+        }
+        spans.clear();
+    }
+};
+
+namespace {
+
+struct ScopedSpan {
+    fs_sim* s; int id; long n;
+    ScopedSpan(fs_sim* s_, int fam, long launches = 1) : s(s_), id(s_->span_begin(fam)), n(launches) {}
+    ~ScopedSpan() { s->span_end(id, n); }
+};
+
+template <class T> T host_cbrt(T v);
+template <> float host_cbrt<float>(float v) { return std::cbrt(v); }     // std::cbrt(float), simulation.cpp:295
+template <> double host_cbrt<double>(double v) { return std::cbrt(v); }
+
+// ---------------------------------------------------------------------------------------
+template <class T>
+struct Engine : EngineBase {
+    fs_sim* S;
+    fs::GridDesc g;       // local slab
+    fs::SlabCtx sc;
+    T* arr[NPOOL] = {nullptr};          // LEAD-shifted pointers
+    int slot[FS_NFIELDS];               // field -> array id (aliases allowed inside a step)
+    bool held[NPOOL] = {false};         // temporaries owned by a running solve
+    uint8_t* flags = nullptr;           // LEAD-shifted
+    bool flags_dirty = true;
+    void* dense = nullptr;              // device staging for pack/unpack: dense local slab, sizeof(double) per cell
+    void* pinned = nullptr;             // host staging for dumps
+    T* gathered = nullptr;              // all-gathered advection source (z-slabs only), LEAD-shifted
+    double* red = nullptr;              // stats scratch
+    static constexpr int NRED = 3 * 1024 + 3;
+
+    explicit Engine(fs_sim* s) : S(s) {}
+
+    long dense_cells() const { return (long)(g.W + 2) * (g.H + 2) * (g.D + 2); }
+
+    int init()
+    {
+        const fs::Comm& cm = S->comm;
+        g.W = S->W; g.H = S->H;
+        g.D = cm.active() ? cm.local_depth(S->D) : S->D;
+        g.sy = ((long)(g.W + 5) + 3) / 4 * 4;
+        g.sz = g.sy * (g.H + 2);
+        g.n = g.sz * (g.D + 2) + 8;    // LEAD + tail so that a dwordx4 at the last ghost stays in bounds
+        g.n = (g.n + 3) / 4 * 4;
+        sc.zoff = cm.active() ? cm.z_offset(S->D) : 0;
+        sc.Dglobal = S->D;
+        sc.lo_wall = (!cm.active() || cm.rank == 0) ? 1 : 0;
+        sc.hi_wall = (!cm.active() || cm.rank == cm.nranks - 1) ? 1 : 0;
+        for (int i = 0; i < NPOOL; ++i) {
+            T* base = nullptr;
+            HIP_TRY(hipMalloc((void**)&base, g.n * sizeof(T)));
+            HIP_TRY(hipMemsetAsync(base, 0, g.n * sizeof(T), S->stream));   // simulation.cpp:38-43
+            arr[i] = base + fs::LEAD;
+        }
+        for (int f = 0; f < FS_NFIELDS; ++f) slot[f] = f;
+        uint8_t* fb = nullptr;
+        HIP_TRY(hipMalloc((void**)&fb, g.n));
+        HIP_TRY(hipMemsetAsync(fb, 0, g.n, S->stream));
+        flags = fb + fs::LEAD;
+        HIP_TRY(hipMalloc(&dense, dense_cells() * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&red, NRED * sizeof(double)));
+        return FS_OK;
+    }
+
+    ~Engine() override
+    {
+        for (int i = 0; i < NPOOL; ++i)
+            if (arr[i]) hipFree(arr[i] - fs::LEAD);
+        if (flags) hipFree(flags - fs::LEAD);
+        if (gathered) hipFree(gathered - fs::LEAD);
+        if (dense) hipFree(dense);
+        if (pinned) hipHostFree(pinned);
+        if (red) hipFree(red);
+    }
+
+    // ---- array pool ------------------------------------------------------------------
+    bool referenced(int id) const
+    {
+        for (int f = 0; f < FS_NFIELDS; ++f)
+            if (slot[f] == id) return true;
+        return held[id];
+    }
+    int acquire(int not_a = -1, int not_b = -1)
+    {
+        for (int i = 0; i < NPOOL; ++i)
+            if (i != not_a && i != not_b && !referenced(i)) { held[i] = true; return i; }
+        return -1;   // cannot happen: NPOOL covers the worst case of a step
+    }
+    bool shared_slot(int f) const
+    {
+        for (int k = 0; k < FS_NFIELDS; ++k)
+            if (k != f && slot[k] == slot[f]) return true;
+        return false;
+    }
+    // give field f an array of its own (same contents)
+    int unalias(int f)
+    {
+        if (!shared_slot(f)) return FS_OK;
+        int id = acquire();
+        if (id < 0) return fail(FS_ENOMEM, "array pool exhausted");
+        fs::launch_copy<T>(S->stream, g, arr[slot[f]], arr[id]);
+        slot[f] = id;
+        held[id] = false;
+        return FS_OK;
+    }
+
+    int ensure_flags()
+    {
+        if (!flags_dirty) return FS_OK;
+        int rc = unalias(FS_OBS);
+        if (rc) return rc;
+        if (S->comm.active()) {
+            rc = S->comm.exchange_halo(S->stream, arr[slot[FS_OBS]], g, sizeof(T));
+            if (rc) return fail(FS_ECOMM, "halo exchange of obs failed: %s", S->comm.last_error());
+        }
+        ScopedSpan sp(S, FAM_MISC);
+        fs::launch_build_flags<T>(S->stream, g, sc, arr[slot[FS_OBS]], flags);
+        flags_dirty = false;
+        return FS_OK;
+    }
+
+    int halo(T* a)
+    {
+        if (!S->comm.active()) return FS_OK;
+        ScopedSpan sp(S, FAM_COMM);
+        int rc = S->comm.exchange_halo(S->stream, a, g, sizeof(T));
+        if (rc) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
+        return FS_OK;
+    }
+
+    // ---- linearSolver (simulation.cpp:251-273) -----------------------------------------
+    // Returns the id of the array holding the result (held); `cur` holds the initial
+    // iterate (may equal rhs when the caller aliased a snapshot).
+    int solve(int b, int cur, int rhs, T a, T c, int sweeps, int* result)
+    {
+        const T inv_c = (T)1 / c;                        // cRecip, :257
+        if (S->solver == FS_SOLVER_GS_LEX) {
+            if (S->comm.active()) return fail(FS_EINVAL, "gs_lex is a single-GPU verification mode");
+            if (cur == rhs) return fail(FS_EINVAL, "gs_lex needs distinct field and prev arrays");
+            ScopedSpan sp(S, FAM_SWEEP, sweeps);
+            if (sweeps > 0) fs::launch_gs_lex<T>(S->stream, g, arr[cur], arr[rhs], flags, b, a, inv_c, sweeps);
+            held[cur] = true;
+            *result = cur;
+            return FS_OK;
+        }
+        int src = cur;
+        bool src_temp = false;
+        for (int it = 0; it < sweeps; ++it) {
+            int dst = acquire(src, rhs);
+            if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
+            {
+                ScopedSpan sp(S, FAM_SWEEP);
+                fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c, 1, g.D);
+            }
+            int rc = halo(arr[dst]);
+            if (rc) return rc;
+            if (src_temp) held[src] = false;
+            src = dst;
+            src_temp = true;
+        }
+        if (!src_temp) held[src] = true;
+        *result = src;
+        return FS_OK;
+    }
+
+    // assign the result of a solve to a field slot
+    void adopt(int field, int id)
+    {
+        slot[field] = id;
+        held[id] = false;
+    }
+
+    T diffusion_a() const
+    {
+        // simulation.cpp:282: dt * diff * width * height * depth, left to right
+        return (T)S->dt * (T)S->diff * (T)S->W * (T)S->H * (T)S->D;
+    }
+
+    int linear_solver(int b, int field, int prev, float a, float c) override
+    {
+        int rc = ensure_flags();
+        if (rc) return rc;
+        if (S->solver == FS_SOLVER_GS_LEX && (rc = unalias(field))) return rc;
+        int res;
+        rc = solve(b, slot[field], slot[prev], (T)a, (T)c, S->acc, &res);
+        if (rc) return rc;
+        adopt(field, res);
+        return FS_OK;
+    }
+
+    int diffuse_T(int b, int field, int prev)
+    {
+        const T a = diffusion_a();
+        int rc = ensure_flags();
+        if (rc) return rc;
+        if (S->solver == FS_SOLVER_GS_LEX && (rc = unalias(field))) return rc;
+        int res;
+        rc = solve(b, slot[field], slot[prev], a, (T)1 + (T)6 * a, S->acc, &res);   // :283
+        if (rc) return rc;
+        adopt(field, res);
+        return FS_OK;
+    }
+    int diffuse(int b, int field, int prev) override { return diffuse_T(b, field, prev); }
+
+    int set_bounds(int b, int field) override
+    {
+        int rc = ensure_flags();
+        if (rc) return rc;
+        if ((rc = unalias(field))) return rc;
+        ScopedSpan sp(S, FAM_BOUNDS, 2);
+        fs::launch_set_bounds<T>(S->stream, g, sc, arr[slot[field]], flags, b);
+        return halo(arr[slot[field]]);
+    }
+
+    // ---- project (simulation.cpp:289-362) ----------------------------------------------
+    int project() override
+    {
+        int rc = ensure_flags();
+        if (rc) return rc;
+        for (int f : { FS_VX, FS_VY, FS_VZ, FS_PRESSURE, FS_DIVERGENCE })
+            if ((rc = unalias(f))) return rc;
+        const T h = (T)1 / host_cbrt<T>((T)(S->W * S->H * S->D));   // :295 (int product, like the reference)
+        {
+            ScopedSpan sp(S, FAM_DIV);
+            fs::launch_divergence<T>(S->stream, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
+                                     arr[slot[FS_DIVERGENCE]], arr[slot[FS_PRESSURE]], flags, (T)(-0.5) * h);
+        }
+        // divergence of the neighbouring slabs' boundary planes is never read (the solve only
+        // reads rhs at the cell itself) and p is zero everywhere, so no exchange is needed here.
+        int res;
+        rc = solve(0, slot[FS_PRESSURE], slot[FS_DIVERGENCE], (T)1, (T)6, S->acc, &res);   // :320
+        if (rc) return rc;
+        adopt(FS_PRESSURE, res);
+        {
+            ScopedSpan sp(S, FAM_GRAD);
+            fs::launch_gradient<T>(S->stream, g, sc, arr[slot[FS_PRESSURE]], arr[slot[FS_VX]], arr[slot[FS_VY]],
+                                   arr[slot[FS_VZ]], flags, h, (T)2 * h);
+        }
+        // the next consumer of v's z-halo planes is the divergence of the second projection
+        // (v_z[z+-1]) and the advection back-trace; refresh them now.
+        for (int f : { FS_VX, FS_VY, FS_VZ })
+            if ((rc = halo(arr[slot[f]]))) return rc;
+        return FS_OK;
+    }
+
+    // ---- advect (simulation.cpp:367-424) ------------------------------------------------
+    int advect(int b, int field, int prev) override
+    {
+        int rc = ensure_flags();
+        if (rc) return rc;
+        if (slot[field] == slot[prev]) {
+            // in-place transport would read its own output: give the field a fresh array
+            int id = acquire();
+            if (id < 0) return fail(FS_ENOMEM, "array pool exhausted");
+            adopt(field, id);
+        }
+        for (int f : { FS_VX, FS_VY, FS_VZ })
+            if (f != field && slot[f] == slot[field]) return fail(FS_EINVAL, "advect target aliases a velocity array");
+        const T kx = (T)S->dt * (T)S->W, ky = (T)S->dt * (T)S->H, kz = (T)S->dt * (T)S->D;   // :384-386
+        const T* src = arr[slot[prev]];
+        long zshift = 0;
+        if (S->comm.active()) {
+            // the back-trace may leave the slab (dt*D*|v_z| planes): gather the whole source
+            if (!gathered) {
+                T* base = nullptr;
+                long n = g.sz * ((long)S->D + 2) + 8;
+                HIP_TRY(hipMalloc((void**)&base, n * sizeof(T)));
+                HIP_TRY(hipMemsetAsync(base, 0, n * sizeof(T), S->stream));
+                gathered = base + fs::LEAD;
+            }
+            ScopedSpan sp(S, FAM_COMM);
+            rc = S->comm.all_gather_planes(S->stream, src, gathered, g, S->D, sizeof(T));
+            if (rc) return fail(FS_ECOMM, "all-gather of the advection source failed: %s", S->comm.last_error());
+            src = gathered;
+            zshift = (long)sc.zoff * g.sz;
+        }
+        {
+            ScopedSpan sp(S, FAM_ADVECT);
+            fs::launch_advect<T>(S->stream, g, sc, b, arr[slot[field]], src, arr[slot[FS_VX]], arr[slot[FS_VY]],
+                                 arr[slot[FS_VZ]], flags, kx, ky, kz, zshift);
+        }
+        return halo(arr[slot[field]]);
+    }
+
+    // ---- step (simulation.cpp:96-150) ---------------------------------------------------
+    int step() override
+    {
+        int rc = ensure_flags();
+        if (rc) return rc;
+        const bool gs = (S->solver == FS_SOLVER_GS_LEX);
+        for (int f : { FS_VX, FS_VY, FS_VZ })
+            if ((rc = unalias(f))) return rc;
+        {
+            ScopedSpan sp(S, FAM_MISC);
+            fs::launch_inlet_velocity<T>(S->stream, g, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
+                                         (T)(float)S->speed);   // :103-105
+        }
+        // :108-110  v_*_prev = v_*  (pre-diffusion snapshot).  Jacobi never writes its input, so
+        // the snapshot is an alias and the copy costs nothing; the in-place mode really copies.
+        const int V[3] = { FS_VX, FS_VY, FS_VZ }, V0[3] = { FS_VX_PREV, FS_VY_PREV, FS_VZ_PREV };
+        for (int k = 0; k < 3; ++k) {
+            if (gs || S->acc <= 0) {
+                if ((rc = unalias(V0[k]))) return rc;
+                ScopedSpan sp(S, FAM_MISC);
+                fs::launch_copy<T>(S->stream, g, arr[slot[V[k]]], arr[slot[V0[k]]]);
+            } else {
+                slot[V0[k]] = slot[V[k]];
+            }
+        }
+        for (int k = 0; k < 3; ++k)                      // :115-117
+            if ((rc = diffuse_T(k + 1, V[k], V0[k]))) return rc;
+        if ((rc = project())) return rc;                 // :120
+        for (int k = 0; k < 3; ++k)                      // :125-127
+            if ((rc = advect(k + 1, V[k], V0[k]))) return rc;
+        if ((rc = project())) return rc;                 // :130
+        if (!S->elide_dead) {                            // :135 (its result is overwritten by :136)
+            if ((rc = diffuse_T(0, FS_DENS, FS_BUFFER))) return rc;
+        }
+        if ((rc = advect(0, FS_DENS, FS_BUFFER))) return rc;   // :136
+        S->step_no++;
+        if (S->in_run && S->dump_every > 0 && (S->step_no % S->dump_every) == 0) return dump_frame();   // :140-148
+        return FS_OK;
+    }
+
+    // one iteration of Simulation::run()'s loop (simulation.cpp:63-71)
+    int run_one() override
+    {
+        int rc = unalias(FS_DENS);
+        if (rc) return rc;
+        {
+            ScopedSpan sp(S, FAM_MISC);
+            fs::launch_inlet_density<T>(S->stream, g, arr[slot[FS_DENS]], (T)0.001f);   // :65-67
+        }
+        if (S->solver == FS_SOLVER_GS_LEX || S->acc <= 0 || S->elide_dead) {
+            if ((rc = unalias(FS_BUFFER))) return rc;
+            ScopedSpan sp(S, FAM_MISC);
+            fs::launch_copy<T>(S->stream, g, arr[slot[FS_DENS]], arr[slot[FS_BUFFER]]);    // :70
+        } else {
+            slot[FS_BUFFER] = slot[FS_DENS];             // :70 as an alias (see step())
+        }
+        return step();
+    }
+
+    // ---- data access ----------------------------------------------------------------
+    int get_field(int which, void* dst, size_t n, int elem) override
+    {
+        if ((long)n != dense_cells()) return fail(FS_EINVAL, "get_field: expected %ld elements, got %zu", dense_cells(), n);
+        const T* f = arr[slot[which]];
+        if (elem == 4) fs::launch_pack<T, float>(S->stream, g, f, (float*)dense, 0, g.D + 1);
+        else if (elem == 8) fs::launch_pack<T, double>(S->stream, g, f, (double*)dense, 0, g.D + 1);
+        else if (elem == 1) fs::launch_pack<T, uint8_t>(S->stream, g, f, (uint8_t*)dense, 0, g.D + 1);
+        else return fail(FS_EINVAL, "elem_size must be 1, 4 or 8");
+        HIP_TRY(hipMemcpyAsync(dst, dense, n * elem, hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        return FS_OK;
+    }
+
+    int set_field(int which, const void* src, size_t n, int elem) override
+    {
+        if ((long)n != dense_cells()) return fail(FS_EINVAL, "set_field: expected %ld elements, got %zu", dense_cells(), n);
+        if (elem != 4 && elem != 8 && elem != 1) return fail(FS_EINVAL, "elem_size must be 1, 4 or 8");
+        // a slot that shares its array gets a fresh one; contents are fully overwritten below
+        if (shared_slot(which)) {
+            int id = acquire();
+            if (id < 0) return fail(FS_ENOMEM, "array pool exhausted");
+            adopt(which, id);
+        }
+        HIP_TRY(hipMemcpyAsync(dense, src, n * elem, hipMemcpyHostToDevice, S->stream));
+        T* f = arr[slot[which]];
+        if (elem == 4) fs::launch_unpack<T, float>(S->stream, g, (const float*)dense, f, 0, g.D + 1);
+        else if (elem == 8) fs::launch_unpack<T, double>(S->stream, g, (const double*)dense, f, 0, g.D + 1);
+        else fs::launch_unpack<T, uint8_t>(S->stream, g, (const uint8_t*)dense, f, 0, g.D + 1);
+        HIP_TRY(hipStreamSynchronize(S->stream));       // `src` may be freed by the caller
+        if (which == FS_OBS) flags_dirty = true;
+        return FS_OK;
+    }
+
+    int set_mask(const uint8_t* mask, size_t n) override { return set_field(FS_OBS, mask, n, 1); }
+
+    int point(int which, int x, int y, int z, float v, int set_instead) override
+    {
+        // x,y are global = local; z is global and must fall into this slab to have an effect
+        int zl = z - sc.zoff;
+        if (zl < 1 || zl > g.D) return FS_OK;
+        int rc = unalias(which);
+        if (rc) return rc;
+        long idx = (long)x + (long)y * g.sy + (long)zl * g.sz;
+        fs::launch_point_add<T>(S->stream, arr[slot[which]], idx, (T)v, set_instead);
+        if (which == FS_OBS) flags_dirty = true;
+        return FS_OK;
+    }
+
+    int apply_solid_cells(const int* cells, long n) override
+    {
+        // cells: device array of packed global cell ids x + y*(W+2) + z*(W+2)*(H+2)
+        int rc = unalias(FS_OBS);
+        if (rc) return rc;
+        fs::launch_mark_cells<T>(S->stream, g, sc, arr[slot[FS_OBS]], cells, n);
+        flags_dirty = true;
+        return FS_OK;
+    }
+
+    int stats(int which, double* out3) override
+    {
+        // whole padded array (simulation.cpp:76, :82-89); a slab counts its own planes plus
+        // the physical ghost planes it holds, and the partial results are all-reduced
+        const int zlo = sc.lo_wall ? 0 : 1, zhi = sc.hi_wall ? g.D + 1 : g.D;
+        fs::launch_stats<T>(S->stream, g, arr[slot[which]], red + 3 * 1024, red, 3 * 1024, zlo, zhi);
+        if (S->comm.active() && S->comm.reduce_stats(S->stream, red + 3 * 1024))
+            return fail(FS_ECOMM, "stats all-reduce failed: %s", S->comm.last_error());
+        HIP_TRY(hipMemcpyAsync(out3, red + 3 * 1024, 3 * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        return FS_OK;
+    }
+
+    // ---- frame dump (simulation.cpp:56-60, 140-148) ---------------------------------------
+    int dump_frame() override
+    {
+        static const char* const names[5] = { "data.bin", "obs.bin", "v_x.bin", "v_y.bin", "v_z.bin" };
+        static const int which[5] = { FS_DENS, FS_OBS, FS_VX, FS_VY, FS_VZ };
+        const long cells = dense_cells();
+        if (!pinned) HIP_TRY(hipHostMalloc(&pinned, cells * sizeof(float), hipHostMallocDefault));
+        if (!S->dump_open) {
+            bool ok = true;
+            for (int k = 0; k < 5; ++k) {
+                std::string path = S->dump_dir + "/" + names[k];
+                // rank 0 truncates like the reference's ofstream::open; other ranks open for update
+                const char* mode = (!S->comm.active() || S->comm.rank == 0) ? "wb" : "r+b";
+                S->dump_fp[k] = fopen(path.c_str(), mode);
+                if (!S->dump_fp[k]) ok = false;
+            }
+            if (!ok) {
+                for (int k = 0; k < 5; ++k)
+                    if (S->dump_fp[k]) { fclose(S->dump_fp[k]); S->dump_fp[k] = nullptr; }
+                if (!S->dump_warned) {
+                    // the reference silently writes nothing when data/ is missing (simulation.cpp:56-60)
+                    fprintf(stderr, "fluidsim: cannot open frame dumps under '%s' -- continuing without dumps\n",
+                            S->dump_dir.c_str());
+                    S->dump_warned = true;
+                }
+                return FS_OK;
+            }
+            S->dump_open = true;
+            S->dump_frames = 0;
+        }
+        // local planes written by this rank: its interior planes, plus the physical ghost planes
+        const int zlo = sc.lo_wall ? 0 : 1, zhi = sc.hi_wall ? g.D + 1 : g.D;
+        const long plane = (long)(g.W + 2) * (g.H + 2);
+        const long frame_cells = plane * ((long)S->D + 2);
+        for (int k = 0; k < 5; ++k) {
+            fs::launch_pack<T, float>(S->stream, g, arr[slot[which[k]]], (float*)dense, zlo, zhi);
+            const long nloc = plane * (zhi - zlo + 1);
+            HIP_TRY(hipMemcpyAsync(pinned, dense, nloc * sizeof(float), hipMemcpyDeviceToHost, S->stream));
+            HIP_TRY(hipStreamSynchronize(S->stream));
+            if (S->comm.active()) {
+                long off = (S->dump_frames * frame_cells + plane * (long)(sc.zoff + zlo)) * (long)sizeof(float);
+                fseek(S->dump_fp[k], off, SEEK_SET);
+            }
+            if (fwrite(pinned, sizeof(float), nloc, S->dump_fp[k]) != (size_t)nloc)
+                return fail(FS_EIO, "short write to %s/%s", S->dump_dir.c_str(), names[k]);
+        }
+        S->dump_frames++;
+        return FS_OK;
+    }
+
+    // ---- measurement ----------------------------------------------------------------
+    int time_sweeps(int b, int field, int prev, float a, float c, int reps, double* ms) override
+    {
+        int rc = ensure_flags();
+        if (rc) return rc;
+        if (reps < 1) return fail(FS_EINVAL, "reps must be >= 1");
+        int s1 = acquire(slot[field], slot[prev]);
+        int s2 = acquire(slot[field], slot[prev]);
+        if (s1 < 0 || s2 < 0) return fail(FS_ENOMEM, "array pool exhausted");
+        const T inv_c = (T)1 / (T)c;
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        // one untimed sweep to fault in code and scratch
+        fs::launch_jacobi<T>(S->stream, g, sc, arr[slot[field]], arr[slot[prev]], arr[s1], flags, b, (T)a, inv_c, 1, g.D);
+        HIP_TRY(hipEventRecord(e0, S->stream));
+        int src = s1, dst = s2;
+        for (int r = 0; r < reps; ++r) {
+            fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c, 1, g.D);
+            int t = src; src = dst; dst = t;
+        }
+        HIP_TRY(hipEventRecord(e1, S->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        *ms = (double)t / reps;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        held[s1] = held[s2] = false;
+        return FS_OK;
+    }
+};
+
+int ensure_engine(fs_sim* s)
+{
+    if (s->eng) return FS_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    int rc;
+    if (s->fp64) {
+        auto* e = new Engine<double>(s);
+        rc = e->init();
+        if (rc) { delete e; return rc; }
+        s->eng = e;
+    } else {
+        auto* e = new Engine<float>(s);
+        rc = e->init();
+        if (rc) { delete e; return rc; }
+        s->eng = e;
+    }
+    return FS_OK;
+}
+
+bool in_box(fs_sim* s, int x, int y, int z) { return x >= 1 && x <= s->W && y >= 1 && y <= s->H && z >= 1 && z <= s->D; }
+
+}  // namespace
+
+// =======================================================================================
+extern "C" {
+
+const char* fs_last_error(void) { return g_err.c_str(); }
+const char* fs_version(void) { return "fluidsim-amd 0.1 (gfx950)"; }
+
+fs_sim* fs_create(int w, int h, int d, int iter, int speed, float dt, float diff, float visc, int acc)
+{
+    if (w < 1 || h < 1 || d < 1 || acc < 0 || iter < 0) {
+        fail(FS_EINVAL, "fs_create: bad extents %dx%dx%d / iter %d / acc %d", w, h, d, iter, acc);
+        return nullptr;
+    }
+    if ((double)(w + 2) * (h + 2) * (d + 2) >= 2147483647.0) {
+        // the reference indexes with int (simulation.h:9,13); keep its limit on the dense layout
+        fail(FS_EINVAL, "fs_create: padded grid exceeds 2^31 cells");
+        return nullptr;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        fail(FS_EHIP, "fs_create: no HIP device available (%s); this library has no CPU path",
+             e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    fs_sim* s = new fs_sim;
+    s->W = w; s->H = h; s->D = d; s->iter = iter; s->speed = speed; s->acc = acc;
+    s->dt = dt; s->diff = diff; s->visc = visc;
+    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
+    e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        fail(FS_EHIP, "fs_create: hipStreamCreate: %s", hipGetErrorString(e));
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+int fs_destroy(fs_sim* s)
+{
+    if (!s) return FS_OK;
+    hipSetDevice(s->device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    s->resolve_spans();
+    for (hipEvent_t ev : s->event_pool) hipEventDestroy(ev);
+    for (int k = 0; k < 5; ++k)
+        if (s->dump_fp[k]) fclose(s->dump_fp[k]);
+    delete s->eng;
+    s->comm.destroy();
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return FS_OK;
+}
+
+int fs_set_option(fs_sim* s, const char* key, const char* value)
+{
+    if (!s || !key || !value) return fail(FS_EINVAL, "fs_set_option: null argument");
+    std::string k = key, v = value;
+    if (k == "precision") {
+        if (s->eng) return fail(FS_EINVAL, "precision must be set before first use");
+        if (v == "fp32") s->fp64 = false;
+        else if (v == "fp64") s->fp64 = true;
+        else return fail(FS_EINVAL, "precision: fp32 | fp64");
+    } else if (k == "solver") {
+        if (v == "jacobi") s->solver = FS_SOLVER_JACOBI;
+        else if (v == "gs_lex") s->solver = FS_SOLVER_GS_LEX;
+        else return fail(FS_EINVAL, "solver: jacobi | gs_lex");
+    } else if (k == "dump_dir") {
+        s->dump_dir = v;
+    } else if (k == "dump_every") {
+        s->dump_every = atoi(value);
+    } else if (k == "voxel_seed") {
+        s->voxel_seed = (unsigned)strtoul(value, nullptr, 10);
+    } else if (k == "quiet") {
+        s->quiet = (v != "0");
+    } else if (k == "profile") {
+        s->profile = (v != "0");
+    } else if (k == "elide_dead_density_solve") {
+        s->elide_dead = (v != "0");
+    } else {
+        return fail(FS_EINVAL, "unknown option '%s'", key);
+    }
+    return FS_OK;
+}
+
+int fs_get_int(fs_sim* s, const char* name, int* out)
+{
+    if (!s || !name || !out) return fail(FS_EINVAL, "null argument");
+    std::string n = name;
+    if (n == "width") *out = s->W; else if (n == "height") *out = s->H; else if (n == "depth") *out = s->D;
+    else if (n == "speed") *out = s->speed; else if (n == "acc") *out = s->acc; else if (n == "iter") *out = s->iter;
+    else if (n == "local_depth") *out = s->comm.active() ? s->comm.local_depth(s->D) : s->D;
+    else if (n == "z_offset") *out = s->comm.active() ? s->comm.z_offset(s->D) : 0;
+    else return fail(FS_EINVAL, "unknown int member '%s'", name);
+    return FS_OK;
+}
+int fs_set_int(fs_sim* s, const char* name, int value)
+{
+    if (!s || !name) return fail(FS_EINVAL, "null argument");
+    std::string n = name;
+    if (n == "speed") s->speed = value;
+    else if (n == "acc") { if (value < 0) return fail(FS_EINVAL, "acc < 0"); s->acc = value; }
+    else if (n == "iter") { if (value < 0) return fail(FS_EINVAL, "iter < 0"); s->iter = value; }
+    else return fail(FS_EINVAL, "member '%s' is fixed after construction", name);
+    return FS_OK;
+}
+int fs_get_float(fs_sim* s, const char* name, float* out)
+{
+    if (!s || !name || !out) return fail(FS_EINVAL, "null argument");
+    std::string n = name;
+    if (n == "dt") *out = s->dt; else if (n == "diff") *out = s->diff; else if (n == "visc") *out = s->visc;
+    else return fail(FS_EINVAL, "unknown float member '%s'", name);
+    return FS_OK;
+}
+int fs_set_float(fs_sim* s, const char* name, float value)
+{
+    if (!s || !name) return fail(FS_EINVAL, "null argument");
+    std::string n = name;
+    if (n == "dt") s->dt = value; else if (n == "diff") s->diff = value; else if (n == "visc") s->visc = value;
+    else return fail(FS_EINVAL, "unknown float member '%s'", name);
+    return FS_OK;
+}
+
+#define ENGINE_OR_RETURN(s)                                  \
+    if (!(s)) return fail(FS_EINVAL, "null handle");         \
+    { int rc_ = ensure_engine(s); if (rc_) return rc_; }     \
+    hipSetDevice((s)->device);
+
+int fs_add_obstacle(fs_sim* s, int x, int y, int z)
+{
+    ENGINE_OR_RETURN(s);
+    if (!in_box(s, x, y, z)) return fail(FS_EINVAL, "addObstacle(%d,%d,%d) outside 1..%dx1..%dx1..%d", x, y, z, s->W, s->H, s->D);
+    return s->eng->point(FS_OBS, x, y, z, 1.0f, 1);
+}
+int fs_add_density(fs_sim* s, int x, int y, int z, float amount)
+{
+    ENGINE_OR_RETURN(s);
+    if (!in_box(s, x, y, z)) return fail(FS_EINVAL, "addDensity(%d,%d,%d) outside the grid", x, y, z);
+    return s->eng->point(FS_DENS, x, y, z, amount, 0);
+}
+int fs_set_velocity(fs_sim* s, int x, int y, int z, float ax, float ay, float az)
+{
+    ENGINE_OR_RETURN(s);
+    if (!in_box(s, x, y, z)) return fail(FS_EINVAL, "setVelocity(%d,%d,%d) outside the grid", x, y, z);
+    int rc = s->eng->point(FS_VX, x, y, z, ax, 1);
+    if (!rc) rc = s->eng->point(FS_VY, x, y, z, ay, 1);
+    if (!rc) rc = s->eng->point(FS_VZ, x, y, z, az, 1);
+    return rc;
+}
+
+int fs_set_obstacle_mask(fs_sim* s, const uint8_t* mask, size_t n)
+{
+    ENGINE_OR_RETURN(s);
+    if (!mask) return fail(FS_EINVAL, "null mask");
+    return s->eng->set_mask(mask, n);
+}
+
+int fs_load_stl(fs_sim* s, const char* stl_file, float scale, float rot_x, float rot_y, float rot_z,
+                float translate_x, float translate_y, float translate_z, long* added)
+{
+    ENGINE_OR_RETURN(s);
+    if (!stl_file) return fail(FS_EINVAL, "null path");
+    fs::VoxelResult vr;
+    int rc = fs::voxelize_stl(s->stream, stl_file, s->W, s->H, s->D, scale, rot_x, rot_y, rot_z, translate_x,
+                              translate_y, translate_z, s->voxel_seed, s->quiet, &vr);
+    if (rc == FS_EIO) return fail(FS_EIO, "%s", vr.error.c_str());
+    if (rc) return fail(rc, "voxelizer: %s", vr.error.c_str());
+    if (added) *added = vr.added;
+    rc = s->eng->apply_solid_cells(vr.d_cells, vr.added);
+    hipStreamSynchronize(s->stream);
+    fs::voxelize_free(&vr);
+    return rc;
+}
+
+int fs_step(fs_sim* s) { ENGINE_OR_RETURN(s); return s->eng->step(); }
+int fs_run_one(fs_sim* s) { ENGINE_OR_RETURN(s); return s->eng->run_one(); }
+
+int fs_sync(fs_sim* s)
+{
+    if (!s) return fail(FS_EINVAL, "null handle");
+    hipSetDevice(s->device);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return FS_OK;
+}
+
+int fs_run(fs_sim* s)
+{
+    ENGINE_OR_RETURN(s);
+    const bool talk = !s->quiet && (!s->comm.active() || s->comm.rank == 0);
+    if (talk) printf("starting 3-D simulation: %dx%dx%d  steps = %d\n", s->W, s->H, s->D, s->iter);   // simulation.cpp:51-53
+    // run() re-opens (truncates) the five files (simulation.cpp:56-60)
+    for (int k = 0; k < 5; ++k)
+        if (s->dump_fp[k]) { fclose(s->dump_fp[k]); s->dump_fp[k] = nullptr; }
+    s->dump_open = false;
+    s->in_run = true;
+    s->step_no = 0;
+    int rc = FS_OK;
+    for (int i = 0; i < s->iter && !rc; ++i) {
+        rc = s->eng->run_one();
+        if (!rc && (i + 1) % 100 == 0 && i > 0) {         // :73-77
+            double st[3];
+            rc = s->eng->stats(FS_DENS, st);
+            if (!rc && talk) printf("step %d\n  density sum = %g\n", i + 1, st[0]);
+        }
+    }
+    if (!rc && s->dump_every == -1) rc = s->eng->dump_frame();
+    s->in_run = false;
+    for (int k = 0; k < 5; ++k)
+        if (s->dump_fp[k]) fflush(s->dump_fp[k]);
+    if (rc) return rc;
+    static const int which[4] = { FS_DENS, FS_VX, FS_VY, FS_VZ };
+    static const char* const label[4] = { "density ", "velocity x", "velocity y", "velocity z" };
+    if (talk) printf("\n--- statistics -------------------------------------------------\n");   // :81
+    for (int k = 0; k < 4; ++k) {
+        double st[3];
+        rc = s->eng->stats(which[k], st);
+        if (rc) return rc;
+        if (talk) printf("%s min = %g\n%s max = %g\n", label[k], st[1], label[k], st[2]);          // :82-89
+    }
+    if (talk) { printf("simulation finished\n"); fflush(stdout); }
+    return FS_OK;
+}
+
+#define CHECK_FIELD(f) if ((f) < 0 || (f) >= FS_NFIELDS) return fail(FS_EINVAL, "bad field selector %d", (f));
+#define CHECK_B(b) if ((b) < 0 || (b) > 3) return fail(FS_EINVAL, "bad boundary code %d", (b));
+
+int fs_set_bounds(fs_sim* s, int b, int field) { ENGINE_OR_RETURN(s); CHECK_B(b); CHECK_FIELD(field); return s->eng->set_bounds(b, field); }
+int fs_linear_solver(fs_sim* s, int b, int field, int prev, float a, float c)
+{
+    ENGINE_OR_RETURN(s); CHECK_B(b); CHECK_FIELD(field); CHECK_FIELD(prev);
+    if (field == prev) return fail(FS_EINVAL, "field and prev must differ");
+    return s->eng->linear_solver(b, field, prev, a, c);
+}
+int fs_diffuse(fs_sim* s, int b, int field, int prev)
+{
+    ENGINE_OR_RETURN(s); CHECK_B(b); CHECK_FIELD(field); CHECK_FIELD(prev);
+    if (field == prev) return fail(FS_EINVAL, "field and prev must differ");
+    return s->eng->diffuse(b, field, prev);
+}
+int fs_project(fs_sim* s) { ENGINE_OR_RETURN(s); return s->eng->project(); }
+int fs_advect(fs_sim* s, int b, int field, int prev)
+{
+    ENGINE_OR_RETURN(s); CHECK_B(b); CHECK_FIELD(field); CHECK_FIELD(prev);
+    if (field == prev) return fail(FS_EINVAL, "field and prev must differ");
+    return s->eng->advect(b, field, prev);
+}
+
+int fs_get_field(fs_sim* s, int which, void* dst, size_t n, int elem_size)
+{
+    ENGINE_OR_RETURN(s); CHECK_FIELD(which);
+    if (!dst) return fail(FS_EINVAL, "null buffer");
+    return s->eng->get_field(which, dst, n, elem_size);
+}
+int fs_set_field(fs_sim* s, int which, const void* src, size_t n, int elem_size)
+{
+    ENGINE_OR_RETURN(s); CHECK_FIELD(which);
+    if (!src) return fail(FS_EINVAL, "null buffer");
+    return s->eng->set_field(which, src, n, elem_size);
+}
+size_t fs_padded_size(fs_sim* s)
+{
+    if (!s) return 0;
+    int d = s->comm.active() ? s->comm.local_depth(s->D) : s->D;
+    return (size_t)(s->W + 2) * (s->H + 2) * (d + 2);
+}
+
+int fs_dump_frame(fs_sim* s) { ENGINE_OR_RETURN(s); return s->eng->dump_frame(); }
+
+int fs_field_stats(fs_sim* s, int which, double* sum, double* mn, double* mx)
+{
+    ENGINE_OR_RETURN(s); CHECK_FIELD(which);
+    double st[3];
+    int rc = s->eng->stats(which, st);
+    if (rc) return rc;
+    if (sum) *sum = st[0];
+    if (mn) *mn = st[1];
+    if (mx) *mx = st[2];
+    return FS_OK;
+}
+
+int fs_get_timing(fs_sim* s, const char* family, double* total_ms, long* launches)
+{
+    if (!s || !family) return fail(FS_EINVAL, "null argument");
+    hipSetDevice(s->device);
+    s->resolve_spans();
+    for (int f = 0; f < FAM_COUNT; ++f)
+        if (strcmp(family, kFamilyNames[f]) == 0) {
+            if (total_ms) *total_ms = s->fam_ms[f];
+            if (launches) *launches = s->fam_launches[f];
+            return FS_OK;
+        }
+    return fail(FS_EINVAL, "unknown kernel family '%s'", family);
+}
+int fs_reset_timing(fs_sim* s)
+{
+    if (!s) return fail(FS_EINVAL, "null handle");
+    hipSetDevice(s->device);
+    s->resolve_spans();
+    for (int f = 0; f < FAM_COUNT; ++f) { s->fam_ms[f] = 0; s->fam_launches[f] = 0; }
+    return FS_OK;
+}
+
+int fs_time_sweeps(fs_sim* s, int b, int field, int prev, float a, float c, int reps, double* ms_per_sweep)
+{
+    ENGINE_OR_RETURN(s); CHECK_B(b); CHECK_FIELD(field); CHECK_FIELD(prev);
+    if (!ms_per_sweep) return fail(FS_EINVAL, "null output");
+    return s->eng->time_sweeps(b, field, prev, a, c, reps, ms_per_sweep);
+}
+
+int fs_comm_unique_id(void* id_out)
+{
+    if (!id_out) return fail(FS_EINVAL, "null id buffer");
+    std::string err;
+    if (fs::Comm::unique_id(id_out, &err)) return fail(FS_ECOMM, "%s", err.c_str());
+    return FS_OK;
+}
+
+int fs_comm_init(fs_sim* s, int rank, int nranks, const void* id)
+{
+    if (!s || !id) return fail(FS_EINVAL, "null argument");
+    if (s->eng) return fail(FS_EINVAL, "fs_comm_init must precede first use of the handle");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(FS_EINVAL, "bad rank %d of %d", rank, nranks);
+    if (s->D % nranks) return fail(FS_EINVAL, "depth %d does not divide over %d slabs", s->D, nranks);
+    if (nranks == 1) return FS_OK;
+    hipSetDevice(s->device);
+    if (s->comm.init(rank, nranks, id)) return fail(FS_ECOMM, "%s", s->comm.last_error());
+    return FS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// kernels.h -- launch interface between the host driver (fluidsim.cpp) and the gfx950
+// kernels (kernels.hip, voxelize.hip).  Internal to libfluidsim.so.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace fs {
+
+// HBM layout of one field (DESIGN.md "Data layout").  Element (x,y,z), 0 <= x <= W+1 etc,
+// lives at p[x + y*sy + z*sz] where p is the allocation base shifted by LEAD elements, so
+// that the first interior cell of every row (x = 1) is 16-byte aligned and a lane can
+// move its four x-consecutive cells with one dwordx4.  sy is a multiple of 4.
+struct GridDesc {
+    int W, H, D;   // interior extents of THIS slab (D = local planes under z-slab partitioning)
+    long sy, sz;   // row and plane pitch in elements
+    long n;        // elements per allocation (including LEAD and the tail pad)
+};
+constexpr int LEAD = 3;
+
+// per-cell flag byte, same indexing as a field
+enum : unsigned {
+    F_SOLID = 1u,        // obs == 1                              (simulation.cpp:222)
+    F_NEAR = 2u,         // fluid cell with an in-range solid 6-neighbour (simulation.cpp:232-238)
+    F_XP = 4u, F_XM = 8u, F_YP = 16u, F_YM = 32u, F_ZP = 64u, F_ZM = 128u   // neighbour in range and obs == 0 (simulation.cpp:307-312)
+};
+
+// z-slab context: global z of local plane 1 is zoff+1; the physical z walls exist only on
+// the first / last slab.
+struct SlabCtx {
+    int zoff;       // global index offset of this slab's planes
+    int Dglobal;    // global depth
+    int lo_wall;    // 1 if local plane 0 is the physical z=0 ghost plane
+    int hi_wall;    // 1 if local plane D+1 is the physical z=Dglobal+1 ghost plane
+};
+
+template <class T>
+void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
+                   const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last);
+
+template <class T>
+void launch_gs_lex(hipStream_t st, const GridDesc& g, T* q, const T* rhs, const uint8_t* flags, int b, T a, T inv_c,
+                   int sweeps);
+
+template <class T>
+void launch_set_bounds(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* q, const uint8_t* flags, int b);
+
+template <class T>
+void launch_divergence(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* vx, const T* vy, const T* vz,
+                       T* div, T* p, const uint8_t* flags, T mhalf_h);
+
+template <class T>
+void launch_gradient(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* p, T* vx, T* vy, T* vz,
+                     const uint8_t* flags, T h, T two_h);
+
+// `prev_zshift` = element offset added to local indices of `prev` (0 normally; under
+// z-slabs `prev` is the all-gathered global array and the shift is zoff planes).
+template <class T>
+void launch_advect(hipStream_t st, const GridDesc& g, const SlabCtx& sc, int b, T* field, const T* prev, const T* vx,
+                   const T* vy, const T* vz, const uint8_t* flags, T kx, T ky, T kz, long prev_zshift);
+
+template <class T>
+void launch_build_flags(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* obs, uint8_t* flags);
+
+template <class T>
+void launch_inlet_velocity(hipStream_t st, const GridDesc& g, T* vx, T* vy, T* vz, T speed);
+template <class T>
+void launch_inlet_density(hipStream_t st, const GridDesc& g, T* dens, T amount);
+
+// dense (reference layout, (W+2)(H+2)(D+2), x fastest) <-> pitched device layout, with
+// element-type conversion.  zlo..zhi (inclusive, local planes) select the planes moved.
+template <class T, class U>
+void launch_pack(hipStream_t st, const GridDesc& g, const T* field, U* dense, int zlo, int zhi);
+template <class T, class U>
+void launch_unpack(hipStream_t st, const GridDesc& g, const U* dense, T* field, int zlo, int zhi);
+
+template <class T>
+void launch_copy(hipStream_t st, const GridDesc& g, const T* src, T* dst);
+
+// sum / min / max over the padded box; out = 3 doubles on the device
+template <class T>
+void launch_stats(hipStream_t st, const GridDesc& g, const T* field, double* out3, double* scratch, int nscratch,
+                  int zlo, int zhi);
+
+template <class T>
+void launch_point_add(hipStream_t st, T* p, long idx, T amount, int set_instead);
+
+}  // namespace fs

@@ -1,0 +1,723 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the wind-tunnel step.
+//
+// Everything here is HBM-bound stencil / gather work (0.67 flop per byte for the sweep), so
+// there is no MFMA anywhere: the design points are 16-byte-per-lane coalesced streams,
+// register/LDS reuse of the six stencil neighbours, wave shuffles for the x neighbours,
+// XCD-aware block order, and boundary handling fused into the producing kernel.
+//
+// Arithmetic follows the reference expression by expression (cited per kernel) and the
+// file is compiled with -ffp-contract=off, so fp32 results are bit-identical with the
+// reference's `c++ -O2` build for the same iteration order.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace fs {
+
+template <class T>
+struct alignas(16) V4 {
+    T e[4];
+};
+
+__device__ __forceinline__ long cell(const GridDesc& g, int x, int y, int z)
+{
+    return (long)x + (long)y * g.sy + (long)z * g.sz;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (block b lands on XCD b % 8, each with its
+// own 4 MiB L2).  Remap so that every XCD owns one contiguous range of work items and
+// y-adjacent tiles, which share halo rows, hit the same L2.  Affects speed only.
+__device__ __forceinline__ int xcd_contiguous(int b, int nblk)
+{
+    int q = nblk >> 3, r = nblk & 7, k = b & 7;
+    return k * q + (k < r ? k : r) + (b >> 3);
+}
+
+// =====================================================================================
+// Jacobi sweep with fused setBounds.
+//   linearSolver  simulation.cpp:251-273 (one iteration of the k loop, neighbours read
+//                 from the previous iterate `src`), followed by
+//   setBounds     simulation.cpp:183-246 applied to the new iterate `dst`.
+//
+// Work decomposition: a wave owns 256 x-consecutive cells (4 per lane, one dwordx4) by RY
+// rows and marches along z keeping planes z-1, z, z+1 of its patch in registers, so each
+// value of `src` is fetched from memory once per sweep (plus halo rows/columns, which are
+// L1/L2 hits).  x neighbours cross lanes with a wave shuffle; only the wave's edge lanes
+// touch memory for them.  A block is four waves stacked in y.
+// =====================================================================================
+template <class T, int RY>
+__global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
+                                                            const T* __restrict__ rhs, T* __restrict__ dst,
+                                                            const uint8_t* __restrict__ flags, int b, T a, T inv_c,
+                                                            int z_first, int z_last, int zc_len, int nxw, int nybg,
+                                                            int nblk)
+{
+    const int v = xcd_contiguous(blockIdx.x, nblk);
+    const int xw = v % nxw;
+    const int ybg = (v / nxw) % nybg;
+    const int zc = v / (nxw * nybg);
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int W = g.W, H = g.H, D = g.D;
+    const int y0 = 1 + (ybg * 4 + wv) * RY;
+    if (y0 > H) return;                                  // wave-uniform
+    const int x0 = 1 + xw * 256 + lane * 4;
+    const bool lane_on = x0 <= W;
+    const int zbeg = z_first + zc * zc_len;
+    const int zend = min(z_last, zbeg + zc_len - 1);
+    if (zbeg > zend) return;
+
+    const bool edge_l = (lane == 0);                     // left neighbour of element 0 comes from memory
+    const bool edge_r = (lane == 63) || (x0 + 4 > W);    // right neighbour of element 3 comes from memory
+    const bool full_group = (x0 + 3 <= W);
+    const unsigned zero_bits = (b == 0) ? F_SOLID : (F_SOLID | F_NEAR);
+    const T zero = (T)0;
+
+    T m[RY][4], c[RY][4], p[RY][4];
+
+    auto load_rows = [&](const T* arr, int z, T (&out)[RY][4], int ymax) {
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            int y = y0 + r;
+            if (lane_on && y <= ymax) {
+                V4<T> q = *reinterpret_cast<const V4<T>*>(arr + cell(g, x0, y, z));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[r][e] = q.e[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[r][e] = zero;
+            }
+        }
+    };
+
+    load_rows(src, zbeg - 1, m, H + 1);
+    load_rows(src, zbeg, c, H + 1);
+
+    for (int z = zbeg; z <= zend; ++z) {
+        load_rows(src, z + 1, p, H + 1);
+        T rv[RY][4];
+        load_rows(rhs, z, rv, H);
+
+        // in-plane halo of the centre plane
+        T hb[4], ht[4];
+        {
+            V4<T> q = {{zero, zero, zero, zero}};
+            if (lane_on) q = *reinterpret_cast<const V4<T>*>(src + cell(g, x0, y0 - 1, z));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hb[e] = q.e[e];
+            V4<T> t = {{zero, zero, zero, zero}};
+            if (lane_on && y0 + RY <= H + 1) t = *reinterpret_cast<const V4<T>*>(src + cell(g, x0, y0 + RY, z));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ht[e] = t.e[e];
+        }
+
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const int y = y0 + r;
+            const bool row_on = (y <= H);                // wave-uniform
+            // x neighbours across lanes (all lanes execute the shuffles)
+            T left = __shfl_up(c[r][3], 1);
+            T right = __shfl_down(c[r][0], 1);
+            if (row_on && lane_on) {
+                const long base = cell(g, x0, y, z);
+                if (edge_l) left = src[base - 1];
+                if (edge_r && full_group) right = src[base + 4];
+                const unsigned fl = *reinterpret_cast<const unsigned*>(flags + base);
+
+                T u[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    T xp1 = (e < 3) ? c[r][e + 1] : right;
+                    T xm1 = (e > 0) ? c[r][e - 1] : left;
+                    T yp1 = (r < RY - 1) ? c[r + 1][e] : ht[e];
+                    T ym1 = (r > 0) ? c[r - 1][e] : hb[e];
+                    // simulation.cpp:264-269: order x+1, x-1, y+1, y-1, z+1, z-1
+                    T nb = xp1 + xm1 + yp1 + ym1 + p[r][e] + m[r][e];
+                    u[e] = (rv[r][e] + a * nb) * inv_c;
+                }
+
+                // ---- fused setBounds on the new iterate (faces read un-zeroed values) ----
+                V4<T> st, gy, gz;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int x = x0 + e;
+                    const bool in = (x <= W);
+                    const bool kill = ((fl >> (8 * e)) & zero_bits) != 0;
+                    T ghost_src = (e > 0) ? u[e - 1] : zero;
+                    st.e[e] = in ? (kill ? zero : u[e]) : ((x == W + 1) ? ghost_src : zero);   // outflow ghost, :191
+                    gy.e[e] = in ? ((b == 2) ? -u[e] : u[e]) : zero;                            // :198-201
+                    gz.e[e] = in ? ((b == 3) ? -u[e] : u[e]) : zero;                            // :208-214
+                }
+                *reinterpret_cast<V4<T>*>(dst + base) = st;
+                if (x0 == 1) dst[base - 1] = (b == 1) ? -u[0] : u[0];                            // :189-190
+                if (full_group && x0 + 3 == W) dst[base + 4] = u[3];                            // :191
+                if (y == 1) *reinterpret_cast<V4<T>*>(dst + base - g.sy) = gy;
+                if (y == H) *reinterpret_cast<V4<T>*>(dst + base + g.sy) = gy;
+                if (z == 1 && sc.lo_wall) *reinterpret_cast<V4<T>*>(dst + base - g.sz) = gz;
+                if (z == D && sc.hi_wall) *reinterpret_cast<V4<T>*>(dst + base + g.sz) = gz;
+            }
+        }
+
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m[r][e] = c[r][e];
+                c[r][e] = p[r][e];
+            }
+    }
+}
+
+template <class T>
+void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
+                   const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last)
+{
+    if (z_last < z_first) return;
+    constexpr int RY = 4;
+    const int nxw = (g.W + 255) / 256;
+    const int nyb = (g.H + RY - 1) / RY;
+    const int nybg = (nyb + 3) / 4;
+    const int planes = z_last - z_first + 1;
+    // enough z chunks for >= ~2048 blocks, but chunks of at least 8 planes (2-plane warm-up each)
+    int zc_len = planes;
+    const long per_layer = (long)nxw * nybg;
+    long want = (2048 + per_layer - 1) / per_layer;
+    if (want < 1) want = 1;
+    zc_len = (int)((planes + want - 1) / want);
+    if (zc_len < 8) zc_len = planes < 8 ? planes : 8;
+    const int nzc = (planes + zc_len - 1) / zc_len;
+    const int nblk = (int)(per_layer * nzc);
+    hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY>), dim3(nblk), dim3(256), 0, st, g, sc, src, rhs, dst, flags, b, a,
+                       inv_c, z_first, z_last, zc_len, nxw, nybg, nblk);
+}
+template void launch_jacobi<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, const float*, float*,
+                                   const uint8_t*, int, float, float, int, int);
+template void launch_jacobi<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, const double*, double*,
+                                    const uint8_t*, int, double, double, int, int);
+
+// =====================================================================================
+// Reference-order in-place sweep (verification mode, single GPU).
+//   linearSolver  simulation.cpp:251-273 at one thread: x outermost, z innermost, in place.
+// Cells on a hyperplane x+y+z = s only depend on hyperplanes s-1 (already updated) and s+1
+// (not yet updated), exactly like the lexicographic sweep, so walking s upward with a
+// barrier between hyperplanes reproduces the reference bit for bit.  One workgroup does
+// the whole solve (all `sweeps` iterations and their setBounds) so that a workgroup
+// barrier is the only synchronisation needed; this mode is for parity, not speed.
+// =====================================================================================
+template <class T>
+__device__ void bounds_in_block(const GridDesc& g, T* q, const uint8_t* flags, int b)
+{
+    const int W = g.W, H = g.H, D = g.D;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int t = tid; t < H * D; t += nt) {
+        int y = 1 + t % H, z = 1 + t / H;
+        T in = q[cell(g, 1, y, z)];
+        q[cell(g, 0, y, z)] = (b == 1) ? -in : in;
+        q[cell(g, W + 1, y, z)] = q[cell(g, W, y, z)];
+    }
+    for (int t = tid; t < W * D; t += nt) {
+        int x = 1 + t % W, z = 1 + t / W;
+        T lo = q[cell(g, x, 1, z)], hi = q[cell(g, x, H, z)];
+        q[cell(g, x, 0, z)] = (b == 2) ? -lo : lo;
+        q[cell(g, x, H + 1, z)] = (b == 2) ? -hi : hi;
+    }
+    for (int t = tid; t < W * H; t += nt) {
+        int x = 1 + t % W, y = 1 + t / W;
+        T lo = q[cell(g, x, y, 1)], hi = q[cell(g, x, y, D)];
+        q[cell(g, x, y, 0)] = (b == 3) ? -lo : lo;
+        q[cell(g, x, y, D + 1)] = (b == 3) ? -hi : hi;
+    }
+    __syncthreads();
+    const unsigned zero_bits = (b == 0) ? F_SOLID : (F_SOLID | F_NEAR);
+    for (long t = tid; t < (long)W * H * D; t += nt) {
+        int x = 1 + (int)(t % W), y = 1 + (int)((t / W) % H), z = 1 + (int)(t / ((long)W * H));
+        long c = cell(g, x, y, z);
+        if (flags[c] & zero_bits) q[c] = (T)0;
+    }
+    __syncthreads();
+}
+
+template <class T>
+__global__ __launch_bounds__(1024) void gs_lex_kernel(GridDesc g, T* q, const T* rhs, const uint8_t* flags, int b, T a,
+                                                       T inv_c, int sweeps)
+{
+    const int W = g.W, H = g.H, D = g.D;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int it = 0; it < sweeps; ++it) {
+        for (int s = 3; s <= W + H + D; ++s) {
+            // y in [max(1, s-W-D) .. min(H, s-2)]
+            for (int t = tid; t < H * D; t += nt) {
+                int y = 1 + t % H, z = 1 + t / H;
+                int x = s - y - z;
+                if (x >= 1 && x <= W) {
+                    long c = cell(g, x, y, z);
+                    T nb = q[c + 1] + q[c - 1] + q[c + g.sy] + q[c - g.sy] + q[c + g.sz] + q[c - g.sz];
+                    q[c] = (rhs[c] + a * nb) * inv_c;
+                }
+            }
+            __syncthreads();
+        }
+        bounds_in_block(g, q, flags, b);
+    }
+}
+
+template <class T>
+void launch_gs_lex(hipStream_t st, const GridDesc& g, T* q, const T* rhs, const uint8_t* flags, int b, T a, T inv_c,
+                   int sweeps)
+{
+    hipLaunchKernelGGL((gs_lex_kernel<T>), dim3(1), dim3(1024), 0, st, g, q, rhs, flags, b, a, inv_c, sweeps);
+}
+template void launch_gs_lex<float>(hipStream_t, const GridDesc&, float*, const float*, const uint8_t*, int, float, float,
+                                   int);
+template void launch_gs_lex<double>(hipStream_t, const GridDesc&, double*, const double*, const uint8_t*, int, double,
+                                    double, int);
+
+// =====================================================================================
+// Stand-alone setBounds (simulation.cpp:183-246): faces first, then the zeroing passes.
+// The hot kernels fuse this; the stand-alone form serves fs_set_bounds and odd callers.
+// =====================================================================================
+template <class T>
+__global__ void bounds_faces_kernel(GridDesc g, SlabCtx sc, T* q, int b)
+{
+    const int W = g.W, H = g.H, D = g.D;
+    const long nx = (long)H * D, ny = (long)W * D, nz = (long)W * H;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < nx + ny + nz; t += (long)gridDim.x * blockDim.x) {
+        if (t < nx) {
+            int y = 1 + (int)(t % H), z = 1 + (int)(t / H);
+            T in = q[cell(g, 1, y, z)];
+            q[cell(g, 0, y, z)] = (b == 1) ? -in : in;
+            q[cell(g, W + 1, y, z)] = q[cell(g, W, y, z)];
+        } else if (t < nx + ny) {
+            long u = t - nx;
+            int x = 1 + (int)(u % W), z = 1 + (int)(u / W);
+            T lo = q[cell(g, x, 1, z)], hi = q[cell(g, x, H, z)];
+            q[cell(g, x, 0, z)] = (b == 2) ? -lo : lo;
+            q[cell(g, x, H + 1, z)] = (b == 2) ? -hi : hi;
+        } else {
+            long u = t - nx - ny;
+            int x = 1 + (int)(u % W), y = 1 + (int)(u / W);
+            if (sc.lo_wall) {
+                T lo = q[cell(g, x, y, 1)];
+                q[cell(g, x, y, 0)] = (b == 3) ? -lo : lo;
+            }
+            if (sc.hi_wall) {
+                T hi = q[cell(g, x, y, D)];
+                q[cell(g, x, y, D + 1)] = (b == 3) ? -hi : hi;
+            }
+        }
+    }
+}
+
+template <class T>
+__global__ void bounds_zero_kernel(GridDesc g, T* q, const uint8_t* flags, int b)
+{
+    const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = 1 + blockIdx.z;
+    if (x > g.W || y > g.H) return;
+    const unsigned zero_bits = (b == 0) ? F_SOLID : (F_SOLID | F_NEAR);
+    long c = cell(g, x, y, z);
+    if (flags[c] & zero_bits) q[c] = (T)0;
+}
+
+static inline dim3 cell_grid(const GridDesc& g) { return dim3((g.W + 63) / 64, (g.H + 3) / 4, g.D); }
+static inline dim3 cell_block() { return dim3(64, 4, 1); }
+
+template <class T>
+void launch_set_bounds(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* q, const uint8_t* flags, int b)
+{
+    long faces = (long)g.H * g.D + (long)g.W * g.D + (long)g.W * g.H;
+    int nb = (int)((faces + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL((bounds_faces_kernel<T>), dim3(nb), dim3(256), 0, st, g, sc, q, b);
+    hipLaunchKernelGGL((bounds_zero_kernel<T>), cell_grid(g), cell_block(), 0, st, g, q, flags, b);
+}
+template void launch_set_bounds<float>(hipStream_t, const GridDesc&, const SlabCtx&, float*, const uint8_t*, int);
+template void launch_set_bounds<double>(hipStream_t, const GridDesc&, const SlabCtx&, double*, const uint8_t*, int);
+
+// Ghost-face writes shared by the per-cell kernels: `u` is the un-zeroed new value of
+// interior cell (x,y,z) of a field with boundary code b (simulation.cpp:187-215).
+template <class T>
+__device__ __forceinline__ void write_face_ghosts(const GridDesc& g, const SlabCtx& sc, T* q, long c, int x, int y,
+                                                  int z, T u, int b)
+{
+    if (x == 1) q[c - 1] = (b == 1) ? -u : u;
+    if (x == g.W) q[c + 1] = u;
+    if (y == 1) q[c - g.sy] = (b == 2) ? -u : u;
+    if (y == g.H) q[c + g.sy] = (b == 2) ? -u : u;
+    if (z == 1 && sc.lo_wall) q[c - g.sz] = (b == 3) ? -u : u;
+    if (z == g.D && sc.hi_wall) q[c + g.sz] = (b == 3) ? -u : u;
+}
+
+// =====================================================================================
+// project, part 1: divergence + pressure reset + setBounds(0,div) + setBounds(0,p)
+//   simulation.cpp:295-319
+// =====================================================================================
+template <class T>
+__global__ __launch_bounds__(256) void divergence_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ vx,
+                                                          const T* __restrict__ vy, const T* __restrict__ vz,
+                                                          T* __restrict__ dv, T* __restrict__ p,
+                                                          const uint8_t* __restrict__ flags, T mhalf_h)
+{
+    const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = 1 + blockIdx.z;
+    if (x > g.W || y > g.H) return;
+    const long c = cell(g, x, y, z);
+    const unsigned f = flags[c];
+    T d = (T)0;
+    if (!(f & F_SOLID)) {
+        T acc = (T)0;                                    // :306-312
+        if (f & F_XP) acc += vx[c + 1];
+        if (f & F_XM) acc -= vx[c - 1];
+        if (f & F_YP) acc += vy[c + g.sy];
+        if (f & F_YM) acc -= vy[c - g.sy];
+        if (f & F_ZP) acc += vz[c + g.sz];
+        if (f & F_ZM) acc -= vz[c - g.sz];
+        d = mhalf_h * acc;                               // (-0.5f*h)*div_val, :314
+    }
+    dv[c] = d;
+    p[c] = (T)0;
+    write_face_ghosts(g, sc, dv, c, x, y, z, d, 0);      // setBounds(0,div): solid cells already hold 0
+    write_face_ghosts(g, sc, p, c, x, y, z, (T)0, 0);    // setBounds(0,p)
+}
+
+template <class T>
+void launch_divergence(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* vx, const T* vy, const T* vz,
+                       T* div, T* p, const uint8_t* flags, T mhalf_h)
+{
+    hipLaunchKernelGGL((divergence_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, div, p, flags,
+                       mhalf_h);
+}
+template void launch_divergence<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, const float*,
+                                       const float*, float*, float*, const uint8_t*, float);
+template void launch_divergence<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, const double*,
+                                        const double*, double*, double*, const uint8_t*, double);
+
+// =====================================================================================
+// project, part 2: v -= grad p, then setBounds(1,vx), (2,vy), (3,vz)
+//   simulation.cpp:322-361
+// =====================================================================================
+template <class T>
+__device__ __forceinline__ T one_sided_grad(bool fp, bool fm, T pp, T pc, T pm, T h, T two_h)
+{
+    if (fp && fm) return (pp - pm) / two_h;              // :329-330
+    if (fp) return (pp - pc) / h;                        // :331-332
+    if (fm) return (pc - pm) / h;                        // :333-334
+    return (T)0;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gradient_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ p,
+                                                        T* __restrict__ vx, T* __restrict__ vy, T* __restrict__ vz,
+                                                        const uint8_t* __restrict__ flags, T h, T two_h)
+{
+    const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = 1 + blockIdx.z;
+    if (x > g.W || y > g.H) return;
+    const long c = cell(g, x, y, z);
+    const unsigned f = flags[c];
+    T ux = vx[c], uy = vy[c], uz = vz[c];
+    if (!(f & F_SOLID)) {
+        const T pc = p[c];
+        ux -= one_sided_grad<T>(f & F_XP, f & F_XM, p[c + 1], pc, p[c - 1], h, two_h);
+        uy -= one_sided_grad<T>(f & F_YP, f & F_YM, p[c + g.sy], pc, p[c - g.sy], h, two_h);
+        uz -= one_sided_grad<T>(f & F_ZP, f & F_ZM, p[c + g.sz], pc, p[c - g.sz], h, two_h);
+    }
+    const bool kill = (f & (F_SOLID | F_NEAR)) != 0;
+    vx[c] = kill ? (T)0 : ux;
+    vy[c] = kill ? (T)0 : uy;
+    vz[c] = kill ? (T)0 : uz;
+    write_face_ghosts(g, sc, vx, c, x, y, z, ux, 1);
+    write_face_ghosts(g, sc, vy, c, x, y, z, uy, 2);
+    write_face_ghosts(g, sc, vz, c, x, y, z, uz, 3);
+}
+
+template <class T>
+void launch_gradient(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* p, T* vx, T* vy, T* vz,
+                     const uint8_t* flags, T h, T two_h)
+{
+    hipLaunchKernelGGL((gradient_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, p, vx, vy, vz, flags, h, two_h);
+}
+template void launch_gradient<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, float*, float*, float*,
+                                     const uint8_t*, float, float);
+template void launch_gradient<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, double*, double*,
+                                      double*, const uint8_t*, double, double);
+
+// =====================================================================================
+// Semi-Lagrangian advection + setBounds(b, field)   simulation.cpp:367-424
+// The back-trace is clamped in GLOBAL coordinates; `prev` may be the all-gathered global
+// array under z-slab partitioning (prev_zshift = zoff planes), see fluidsim.cpp.
+// =====================================================================================
+template <class T>
+__device__ __forceinline__ T clamp_ref(T v, T lo, T hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }   // std::clamp
+
+template <class T>
+__global__ __launch_bounds__(256) void advect_kernel(GridDesc g, SlabCtx sc, int b, T* __restrict__ field,
+                                                      const T* __restrict__ prev, const T* vx, const T* vy,
+                                                      const T* vz, const uint8_t* __restrict__ flags, T kx, T ky, T kz,
+                                                      long prev_zshift)
+{
+    const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = 1 + blockIdx.z;
+    if (x > g.W || y > g.H) return;
+    const long c = cell(g, x, y, z);
+    const unsigned f = flags[c];
+    const T one = (T)1, half = (T)0.5;
+    T u = (T)0;
+    if (!(f & F_SOLID)) {
+        const T own = prev[c + prev_zshift];
+        const T ux = (b == 1) ? own : vx[c];             // :380-382
+        const T uy = (b == 2) ? own : vy[c];
+        const T uz = (b == 3) ? own : vz[c];
+        const int zg = z + sc.zoff;                      // global plane index
+        T px = clamp_ref<T>((T)x - kx * ux, half, (T)g.W + half);          // :384-390
+        T py = clamp_ref<T>((T)y - ky * uy, half, (T)g.H + half);
+        T pz = clamp_ref<T>((T)zg - kz * uz, half, (T)sc.Dglobal + half);
+        const int x0 = (int)floor(px), y0 = (int)floor(py), z0 = (int)floor(pz);
+        const T tx = px - (T)x0, ty = py - (T)y0, tz = pz - (T)z0;
+        const T* s = prev + prev_zshift + cell(g, x0, y0, z0 - sc.zoff);
+        const T a00 = s[0] * (one - tx) + s[1] * tx;                          // :412-415
+        const T a01 = s[g.sz] * (one - tx) + s[g.sz + 1] * tx;
+        const T a10 = s[g.sy] * (one - tx) + s[g.sy + 1] * tx;
+        const T a11 = s[g.sy + g.sz] * (one - tx) + s[g.sy + g.sz + 1] * tx;
+        const T b0 = a00 * (one - ty) + a10 * ty;                             // :417-418
+        const T b1 = a01 * (one - ty) + a11 * ty;
+        u = b0 * (one - tz) + b1 * tz;                                        // :420
+    }
+    const bool kill = (b != 0) && (f & F_NEAR);
+    field[c] = kill ? (T)0 : u;
+    write_face_ghosts(g, sc, field, c, x, y, z, u, b);
+}
+
+template <class T>
+void launch_advect(hipStream_t st, const GridDesc& g, const SlabCtx& sc, int b, T* field, const T* prev, const T* vx,
+                   const T* vy, const T* vz, const uint8_t* flags, T kx, T ky, T kz, long prev_zshift)
+{
+    hipLaunchKernelGGL((advect_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, b, field, prev, vx, vy, vz, flags,
+                       kx, ky, kz, prev_zshift);
+}
+template void launch_advect<float>(hipStream_t, const GridDesc&, const SlabCtx&, int, float*, const float*, const float*,
+                                   const float*, const float*, const uint8_t*, float, float, float, long);
+template void launch_advect<double>(hipStream_t, const GridDesc&, const SlabCtx&, int, double*, const double*,
+                                    const double*, const double*, const double*, const uint8_t*, double, double, double,
+                                    long);
+
+// =====================================================================================
+// Flag bytes from the obstacle array.  Tests follow the reference literally:
+// solid <=> obs == 1 (simulation.cpp:222), fluid neighbour <=> in range && obs == 0 (:307).
+// Under z-slabs "in range" refers to the global depth; the halo planes of `obs` hold the
+// neighbouring slabs' cells.
+// =====================================================================================
+template <class T>
+__global__ void build_flags_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ obs, uint8_t* __restrict__ flags)
+{
+    const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = 1 + blockIdx.z;
+    if (x > g.W || y > g.H) return;
+    const long c = cell(g, x, y, z);
+    const int zg = z + sc.zoff;
+    const bool rxp = x + 1 <= g.W, rxm = x - 1 >= 1, ryp = y + 1 <= g.H, rym = y - 1 >= 1;
+    const bool rzp = zg + 1 <= sc.Dglobal, rzm = zg - 1 >= 1;
+    const T one = (T)1, zero = (T)0;
+    unsigned f = 0;
+    if (obs[c] == one) {
+        f = F_SOLID;
+    } else {
+        bool near = (rxp && obs[c + 1] == one) || (rxm && obs[c - 1] == one) || (ryp && obs[c + g.sy] == one) ||
+                    (rym && obs[c - g.sy] == one) || (rzp && obs[c + g.sz] == one) || (rzm && obs[c - g.sz] == one);
+        if (near) f |= F_NEAR;
+    }
+    if (rxp && obs[c + 1] == zero) f |= F_XP;
+    if (rxm && obs[c - 1] == zero) f |= F_XM;
+    if (ryp && obs[c + g.sy] == zero) f |= F_YP;
+    if (rym && obs[c - g.sy] == zero) f |= F_YM;
+    if (rzp && obs[c + g.sz] == zero) f |= F_ZP;
+    if (rzm && obs[c - g.sz] == zero) f |= F_ZM;
+    flags[c] = (uint8_t)f;
+}
+
+template <class T>
+void launch_build_flags(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* obs, uint8_t* flags)
+{
+    hipLaunchKernelGGL((build_flags_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, obs, flags);
+}
+template void launch_build_flags<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, uint8_t*);
+template void launch_build_flags<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, uint8_t*);
+
+// =====================================================================================
+// Inlet forcing: velocity (speed,0,0) on the x=1 face (simulation.cpp:103-105) and
+// +amount density on the same face (simulation.cpp:65-67).
+// =====================================================================================
+template <class T>
+__global__ void inlet_velocity_kernel(GridDesc g, T* vx, T* vy, T* vz, T speed)
+{
+    const int y = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int z = 1 + blockIdx.y;
+    if (y > g.H) return;
+    const long c = cell(g, 1, y, z);
+    vx[c] = speed;
+    vy[c] = (T)0;
+    vz[c] = (T)0;
+}
+template <class T>
+__global__ void inlet_density_kernel(GridDesc g, T* dens, T amount)
+{
+    const int y = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int z = 1 + blockIdx.y;
+    if (y > g.H) return;
+    dens[cell(g, 1, y, z)] += amount;
+}
+template <class T>
+void launch_inlet_velocity(hipStream_t st, const GridDesc& g, T* vx, T* vy, T* vz, T speed)
+{
+    hipLaunchKernelGGL((inlet_velocity_kernel<T>), dim3((g.H + 63) / 64, g.D), dim3(64), 0, st, g, vx, vy, vz, speed);
+}
+template <class T>
+void launch_inlet_density(hipStream_t st, const GridDesc& g, T* dens, T amount)
+{
+    hipLaunchKernelGGL((inlet_density_kernel<T>), dim3((g.H + 63) / 64, g.D), dim3(64), 0, st, g, dens, amount);
+}
+template void launch_inlet_velocity<float>(hipStream_t, const GridDesc&, float*, float*, float*, float);
+template void launch_inlet_velocity<double>(hipStream_t, const GridDesc&, double*, double*, double*, double);
+template void launch_inlet_density<float>(hipStream_t, const GridDesc&, float*, float);
+template void launch_inlet_density<double>(hipStream_t, const GridDesc&, double*, double);
+
+// =====================================================================================
+// Layout conversion: pitched device field <-> the reference's dense padded array
+// (simulation.h:9, the frame-dump layout of simulation.cpp:143-147).
+// =====================================================================================
+template <class T, class U>
+__global__ void pack_kernel(GridDesc g, const T* __restrict__ f, U* __restrict__ dense, int zlo)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = zlo + blockIdx.z;
+    if (x > g.W + 1 || y > g.H + 1) return;
+    dense[(long)x + (long)y * (g.W + 2) + (long)(z - zlo) * (g.W + 2) * (g.H + 2)] = (U)f[cell(g, x, y, z)];
+}
+template <class T, class U>
+__global__ void unpack_kernel(GridDesc g, const U* __restrict__ dense, T* __restrict__ f, int zlo)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = zlo + blockIdx.z;
+    if (x > g.W + 1 || y > g.H + 1) return;
+    f[cell(g, x, y, z)] = (T)dense[(long)x + (long)y * (g.W + 2) + (long)(z - zlo) * (g.W + 2) * (g.H + 2)];
+}
+template <class T, class U>
+void launch_pack(hipStream_t st, const GridDesc& g, const T* field, U* dense, int zlo, int zhi)
+{
+    if (zhi < zlo) return;
+    hipLaunchKernelGGL((pack_kernel<T, U>), dim3((g.W + 2 + 63) / 64, (g.H + 2 + 3) / 4, zhi - zlo + 1), dim3(64, 4, 1),
+                       0, st, g, field, dense, zlo);
+}
+template <class T, class U>
+void launch_unpack(hipStream_t st, const GridDesc& g, const U* dense, T* field, int zlo, int zhi)
+{
+    if (zhi < zlo) return;
+    hipLaunchKernelGGL((unpack_kernel<T, U>), dim3((g.W + 2 + 63) / 64, (g.H + 2 + 3) / 4, zhi - zlo + 1),
+                       dim3(64, 4, 1), 0, st, g, dense, field, zlo);
+}
+#define FS_INST_PACK(T, U)                                                                     \
+    template void launch_pack<T, U>(hipStream_t, const GridDesc&, const T*, U*, int, int);     \
+    template void launch_unpack<T, U>(hipStream_t, const GridDesc&, const U*, T*, int, int);
+FS_INST_PACK(float, float)
+FS_INST_PACK(float, double)
+FS_INST_PACK(double, float)
+FS_INST_PACK(double, double)
+FS_INST_PACK(float, uint8_t)
+FS_INST_PACK(double, uint8_t)
+
+template <class T>
+__global__ void copy_kernel(const T* __restrict__ src, T* __restrict__ dst, long n4)
+{
+    // whole allocation, 16 B per lane (allocation length is a multiple of 4 elements)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<V4<T>*>(dst)[i] = reinterpret_cast<const V4<T>*>(src)[i];
+}
+template <class T>
+void launch_copy(hipStream_t st, const GridDesc& g, const T* src, T* dst)
+{
+    // src/dst are the LEAD-shifted pointers; copy the underlying allocations
+    long n4 = g.n / 4;
+    hipLaunchKernelGGL((copy_kernel<T>), dim3(2048), dim3(256), 0, st, src - LEAD, dst - LEAD, n4);
+}
+template void launch_copy<float>(hipStream_t, const GridDesc&, const float*, float*);
+template void launch_copy<double>(hipStream_t, const GridDesc&, const double*, double*);
+
+// =====================================================================================
+// Diagnostics of Simulation::run(): sum / min / max of a whole padded array
+// (simulation.cpp:73-90).  Two-stage reduction in double.
+// =====================================================================================
+template <class T>
+__global__ __launch_bounds__(256) void stats_partial_kernel(GridDesc g, const T* __restrict__ f, double* part, int zlo,
+                                                             int zhi)
+{
+    const long rows = (long)(g.H + 2) * (zhi - zlo + 1);
+    double s = 0.0, mn = 1e300, mx = -1e300;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        int y = (int)(r % (g.H + 2)), z = zlo + (int)(r / (g.H + 2));
+        for (int x = threadIdx.x; x <= g.W + 1; x += blockDim.x) {
+            double v = (double)f[cell(g, x, y, z)];
+            s += v;
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+    }
+    __shared__ double sh[3][256];
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = mn; sh[2][threadIdx.x] = mx;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + k];
+            sh[1][threadIdx.x] = fmin(sh[1][threadIdx.x], sh[1][threadIdx.x + k]);
+            sh[2][threadIdx.x] = fmax(sh[2][threadIdx.x], sh[2][threadIdx.x + k]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[3 * blockIdx.x + 0] = sh[0][0];
+        part[3 * blockIdx.x + 1] = sh[1][0];
+        part[3 * blockIdx.x + 2] = sh[2][0];
+    }
+}
+__global__ void stats_final_kernel(const double* part, int n, double* out3)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0, mn = 1e300, mx = -1e300;
+    for (int i = 0; i < n; ++i) {
+        s += part[3 * i];
+        mn = fmin(mn, part[3 * i + 1]);
+        mx = fmax(mx, part[3 * i + 2]);
+    }
+    out3[0] = s; out3[1] = mn; out3[2] = mx;
+}
+template <class T>
+void launch_stats(hipStream_t st, const GridDesc& g, const T* field, double* out3, double* scratch, int nscratch,
+                  int zlo, int zhi)
+{
+    int nb = nscratch / 3;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL((stats_partial_kernel<T>), dim3(nb), dim3(256), 0, st, g, field, scratch, zlo, zhi);
+    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(64), 0, st, scratch, nb, out3);
+}
+template void launch_stats<float>(hipStream_t, const GridDesc&, const float*, double*, double*, int, int, int);
+template void launch_stats<double>(hipStream_t, const GridDesc&, const double*, double*, double*, int, int, int);
+
+template <class T>
+__global__ void point_kernel(T* p, long idx, T amount, int set_instead)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = set_instead ? amount : p[idx] + amount;
+}
+template <class T>
+void launch_point_add(hipStream_t st, T* p, long idx, T amount, int set_instead)
+{
+    hipLaunchKernelGGL((point_kernel<T>), dim3(1), dim3(64), 0, st, p, idx, amount, set_instead);
+}
+template void launch_point_add<float>(hipStream_t, float*, long, float, int);
+template void launch_point_add<double>(hipStream_t, double*, long, double, int);
+
+}  // namespace fs

@@ -1,0 +1,173 @@
+/* include/fluidsim.h -- C ABI of libfluidsim.so, the MI355X-native wind-tunnel solver.
+ *
+ * The reference (Ghundi/fluid_simulation) has no FFI or plugin interface; its seams are a
+ * C++ class, one free function, a no-argument executable and a file layout (SURVEY.md
+ * section 8b).  This header is the drop-in boundary for the first two: one handle type
+ * and one function per public member of `class Simulation` (simulation.h:42-91) and for
+ * loadSTLIntoObstacles (object_loader.h:7-17), with the same argument order, the same
+ * 1-based interior coordinates and the same defaults.  Every entry point cites the
+ * reference declaration it replaces.  Plain C types only; no device pointers cross.
+ *
+ * All compute happens in hand-written HIP kernels for gfx950; there is no CPU fallback.
+ * fs_create fails (NULL + fs_last_error) when no HIP device is usable.
+ *
+ * Return convention: 0 on success, a negative FS_E* code on failure; fs_last_error()
+ * describes the most recent failure on the calling thread.  The reference itself has no
+ * error reporting (out-of-range mutators are UB there, simulation.cpp:157-177); here
+ * they are FS_EINVAL.  A handle is driven by one host thread at a time.
+ */
+#ifndef FLUIDSIM_H
+#define FLUIDSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fs_sim fs_sim;
+
+enum {
+    FS_OK = 0,
+    FS_EINVAL = -1,   /* bad argument / out-of-range cell / call not legal in this state */
+    FS_EIO = -2,      /* STL or dump-file I/O */
+    FS_EHIP = -3,     /* HIP runtime error (no device, allocation, launch) */
+    FS_ECOMM = -4,    /* RCCL error (multi-GPU slabs) */
+    FS_ENOMEM = -5
+};
+
+/* Field selectors for fs_get_field / fs_set_field and the per-pass entry points.  The
+ * order of 0..4 is the frame-dump order of simulation.cpp:143-147 with obs at 4; 5..10
+ * are the reference's private scratch arrays (simulation.h:16-27). */
+enum {
+    FS_DENS = 0, FS_VX = 1, FS_VY = 2, FS_VZ = 3, FS_OBS = 4,
+    FS_PRESSURE = 5, FS_DIVERGENCE = 6,
+    FS_VX_PREV = 7, FS_VY_PREV = 8, FS_VZ_PREV = 9, FS_BUFFER = 10,
+    FS_NFIELDS = 11
+};
+
+/* Solver used by linearSolver (simulation.cpp:251-273). */
+enum {
+    FS_SOLVER_JACOBI = 0,  /* ping-pong Jacobi, any grid, multi-GPU capable (default) */
+    FS_SOLVER_GS_LEX = 1   /* the reference's in-place sweep in its one-thread order; verification mode */
+};
+
+/* ---- construction -------------------------------------------------------------- */
+
+/* Simulation::Simulation(w,h,d,iter,speed=30,dt=0.05f,diff=2.0e-5f,visc=1.5e-5f,acc=15)
+ * -- simulation.h:59-64, simulation.cpp:17-44.  Uses the calling thread's current HIP
+ * device.  Fields are zero-initialised; storage is allocated on first use so that
+ * fs_set_option("precision", ...) can still be applied. */
+fs_sim* fs_create(int w, int h, int d, int iter, int speed, float dt, float diff, float visc, int acc);
+
+/* Reference defaults for the trailing constructor arguments (simulation.h:60-64). */
+#define FS_DEFAULT_SPEED 30
+#define FS_DEFAULT_DT 0.05f
+#define FS_DEFAULT_DIFF 2.0e-5f
+#define FS_DEFAULT_VISC 1.5e-5f
+#define FS_DEFAULT_ACC 15
+
+int fs_destroy(fs_sim* s);
+
+/* Options (string key/value), legal before the first step unless noted:
+ *   "precision"   "fp32" (default) | "fp64"       field storage + arithmetic; before first use only
+ *   "solver"      "jacobi" (default) | "gs_lex"
+ *   "dump_dir"    directory for frame dumps, default "data" (simulation.cpp:56-60)
+ *   "dump_every"  N>=1 dump every Nth step (default 1 = reference behaviour), 0 = never,
+ *                 -1 = last step of fs_run only.  May be changed at any time.
+ *   "voxel_seed"  seed of the voxelizer's minstd_rand stream (object_loader.cpp:399 uses a
+ *                 thread-id hash; default here is 1)
+ *   "quiet"       "1" suppresses the reference's console lines
+ *   "profile"     "1" brackets each kernel family with HIP events (see fs_get_timing)
+ *   "elide_dead_density_solve" "1" skips diffuse(0,dens,buffer) whose result the next
+ *                 advect overwrites (simulation.cpp:135-136); default "0" = do it
+ */
+int fs_set_option(fs_sim* s, const char* key, const char* value);
+
+/* Public data members of class Simulation (simulation.h:44-54), by name:
+ * "width" "height" "depth" "speed" "acc" "iter" (int) and "dt" "diff" "visc" (float). */
+int fs_get_int(fs_sim* s, const char* name, int* out);
+int fs_set_int(fs_sim* s, const char* name, int value);      /* speed, acc, iter only */
+int fs_get_float(fs_sim* s, const char* name, float* out);
+int fs_set_float(fs_sim* s, const char* name, float value);
+
+/* ---- mutators (1-based interior coordinates, like the reference) ---------------- */
+
+int fs_add_obstacle(fs_sim* s, int x, int y, int z);                          /* Simulation::addObstacle  simulation.h:79, .cpp:155-158 */
+int fs_add_density(fs_sim* s, int x, int y, int z, float amount);             /* Simulation::addDensity   simulation.h:84, .cpp:163-166 */
+int fs_set_velocity(fs_sim* s, int x, int y, int z, float ax, float ay, float az); /* Simulation::setVelocity simulation.h:89, .cpp:171-178 */
+
+/* loadSTLIntoObstacles(stlFile, sim, scale=0.8f, rot_x, rot_y, rot_z, translate_x/y/z)
+ * -- object_loader.h:7-17, object_loader.cpp:270-452.  Ray-parity voxelisation runs on
+ * the GPU.  A missing or empty STL prints the reference's message, leaves the tunnel
+ * unchanged and returns FS_EIO (the reference returns void and carries on,
+ * object_loader.cpp:282-285; callers that want that behaviour ignore the code).
+ * On success *added (may be NULL) receives the "Added N obstacle points" count. */
+int fs_load_stl(fs_sim* s, const char* stl_file, float scale, float rot_x, float rot_y, float rot_z,
+                float translate_x, float translate_y, float translate_z, long* added);
+
+/* Whole-mask injection (golden masks, analytic shapes): `mask` is a padded x-fastest
+ * array of (w+2)(h+2)(d+2) bytes, non-zero = solid; ghost cells must be zero. */
+int fs_set_obstacle_mask(fs_sim* s, const uint8_t* mask, size_t n);
+
+/* ---- time stepping -------------------------------------------------------------- */
+
+int fs_step(fs_sim* s);     /* Simulation::step()  simulation.h:74, .cpp:96-150 (incl. the frame dump, subject to dump_every) */
+int fs_run_one(fs_sim* s);  /* one iteration of the loop in Simulation::run(): inlet density, buffer=dens, step()  .cpp:63-78 */
+int fs_run(fs_sim* s);      /* Simulation::run()   simulation.h:69, .cpp:49-91: `iter` iterations + the console statistics */
+int fs_sync(fs_sim* s);     /* wait for all queued GPU work of this handle */
+
+/* The private passes of the reference, exposed for per-kernel parity tests.  `field` and
+ * `prev` are FS_* selectors; b is the boundary code (0 scalar, 1/2/3 velocity component). */
+int fs_set_bounds(fs_sim* s, int b, int field);                                  /* setBounds     simulation.cpp:183-246 */
+int fs_linear_solver(fs_sim* s, int b, int field, int prev, float a, float c);   /* linearSolver  simulation.cpp:251-273 */
+int fs_diffuse(fs_sim* s, int b, int field, int prev);                           /* diffuse       simulation.cpp:278-284 */
+int fs_project(fs_sim* s);                                                       /* project       simulation.cpp:289-362 */
+int fs_advect(fs_sim* s, int b, int field, int prev);                            /* advect        simulation.cpp:367-424 */
+
+/* ---- data access ---------------------------------------------------------------- */
+
+/* Copies one field in the reference's own layout: padded (w+2)(h+2)(d+2), x fastest
+ * (simulation.h:9).  elem_size selects the host element type (4 = float, 8 = double);
+ * conversion happens on the device.  n is the element count of the host buffer. */
+int fs_get_field(fs_sim* s, int which, void* dst, size_t n, int elem_size);
+int fs_set_field(fs_sim* s, int which, const void* src, size_t n, int elem_size);
+size_t fs_padded_size(fs_sim* s);   /* Simulation::size  simulation.cpp:35 */
+
+/* Append one frame to <dump_dir>/{data,obs,v_x,v_y,v_z}.bin exactly as simulation.cpp:140-148. */
+int fs_dump_frame(fs_sim* s);
+
+/* Diagnostics of run(): sum/min/max over the whole padded array (simulation.cpp:73-90). */
+int fs_field_stats(fs_sim* s, int which, double* sum, double* min, double* max);
+
+/* ---- measurement ---------------------------------------------------------------- */
+
+/* With option "profile"="1": accumulated HIP-event time and launch count of one kernel
+ * family since the last fs_reset_timing: "sweep" "divergence" "gradient" "advect"
+ * "bounds" "misc".  Events are recorded on the handle's own stream. */
+int fs_get_timing(fs_sim* s, const char* family, double* total_ms, long* launches);
+int fs_reset_timing(fs_sim* s);
+
+/* Times `reps` back-to-back linearSolver sweeps (b, a, c as fs_linear_solver) on the
+ * current state with HIP events on the handle's stream, without changing the state
+ * (scratch output).  Writes the mean milliseconds per sweep. */
+int fs_time_sweeps(fs_sim* s, int b, int field, int prev, float a, float c, int reps, double* ms_per_sweep);
+
+/* ---- multi-GPU z-slabs (one process per GPU; RCCL halo exchange over xGMI) -------- */
+
+/* Size of the opaque RCCL unique id; rank 0 fills it with fs_comm_unique_id and the
+ * host layer broadcasts it to the other ranks (e.g. through torch.distributed). */
+#define FS_COMM_ID_BYTES 128
+int fs_comm_unique_id(void* id_out);
+/* Turns the handle into the owner of z-slab `rank` of `nranks` of the global grid given
+ * to fs_create (depth must divide evenly).  Must precede first use. */
+int fs_comm_init(fs_sim* s, int rank, int nranks, const void* id);
+
+const char* fs_last_error(void);
+const char* fs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDSIM_H */
