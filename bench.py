@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- the north-star metric on synthetic wind tunnels (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|c2|c3|c4]
+
+A "step" is one iteration of the reference's time loop (Simulation::run(), simulation.cpp:63-71:
+inlet density, buffer = dens, Simulation::step()) with frame dumps off.  Fields live in HBM for
+the whole timed region.  Workloads (BASELINE.json configs):
+    c2  256^3,          sphere,         40 solver iterations
+    c3  512^3,          sphere + plate, 80 solver iterations   <- N=1 default ("roofline run")
+    c4  1024x512x512,   sphere + plate, 80 solver iterations   <- N>1 default, z-slabs, strong scaling
+For N>1 the driver launches one rank per GPU with torch.distributed.run; ranks exchange halo
+planes over RCCL inside libfluidsim.so.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+SWEEP_BYTES_PER_CELL = 12    # read x, read rhs, write x (fp32)
+
+WORKLOADS = {
+    "c2": dict(W=256, H=256, D=256, acc=40, plate=False),
+    "c3": dict(W=512, H=512, D=512, acc=80, plate=True),
+    "c4": dict(W=1024, H=512, D=512, acc=80, plate=True),
+}
+
+
+def add_obstacles(F, sim, cfg, tmp):
+    """Synthetic STL meshes through the reference's loader path (object_loader.cpp:270-452).
+    Mesh units are chosen so the loader samples at its finest grid (200^3)."""
+    from fluid_simulation_amd import shapes
+    W, H, D = cfg["W"], cfg["H"], cfg["D"]
+    sphere = shapes.write_binary_stl(os.path.join(tmp, "sphere.stl"), shapes.sphere_triangles(2.0, 48, 24))
+    added = [F.loadSTLIntoObstacles(sphere, sim, 0.3, 0.0, 0.0, 0.0, -W / 4.0, 0.0, 0.0)]
+    if cfg["plate"]:
+        plate = shapes.write_binary_stl(os.path.join(tmp, "plate.stl"), shapes.box_triangles(0.2, 2.4, 1.6))
+        added.append(F.loadSTLIntoObstacles(plate, sim, 0.45, 0.0, 0.0, 0.0, W / 8.0, 0.0, 0.0))
+    return added
+
+
+def cpu_baseline(acc, budget_s=12.0):
+    """Reference CPU path timed on this box's host cores, on a bounded sample of the same kind
+    of workload: a 64^3 tunnel with a ball obstacle at the workload's iteration count, stepped
+    until ~budget_s seconds have passed.  Uses the compiled reference (oracle/_ref/libref.so,
+    "reference") when it travelled with the repo, else the C restatement ("port")."""
+    import numpy as np
+    from oracle import cpu_ref as O
+    O.build()
+    W = H = D = 64
+    # the box's CPU share for one GPU is 16 cores even where os.cpu_count() reports the whole host
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("FS_CPU_BASELINE_THREADS", "16"))))
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    z, y, x = np.mgrid[0:D + 2, 0:H + 2, 0:W + 2]
+    mask = ((x - 16) ** 2 + (y - 32) ** 2 + (z - 32) ** 2) <= 64
+    if O.have_reference():
+        kind, sim = "reference", O.Reference(W, H, D, iter=1, acc=acc)
+    else:
+        kind, sim = "port", O.Oracle(W, H, D, solver=O.GS_LEX, threads=cores, iter=1, acc=acc)
+    sim.set_mask(mask)
+    sim.run_one()                       # warm caches / thread pool
+    n, t0 = 0, time.perf_counter()
+    while True:
+        sim.run_one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 200:
+            break
+    return {
+        "value": W * H * D * n / el, "unit": "cells*steps/s", "cores": cores, "kind": kind,
+        "sample": "64x64x64 tunnel, ball obstacle r=8, acc=%d, %d steps in %.1f s, OpenMP %d threads, dumps off"
+                  % (acc, n, el, cores),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "c4"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no HIP device visible); the solver has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import fluid_simulation_amd as F
+
+    name = args.workload
+    if name == "auto":
+        name = "c3" if world == 1 else "c4"
+    cfg = WORKLOADS[name]
+    W, H, D, acc = cfg["W"], cfg["H"], cfg["D"], cfg["acc"]
+    cells = W * H * D
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sim = F.Simulation(W, H, D, args.steps, acc=acc, precision=args.precision, quiet=1, dump_every=0, profile=1)
+    if world > 1:
+        ids = [F.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        sim.comm_init(rank, world, ids[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        added = add_obstacles(F, sim, cfg, tmp)
+
+    for _ in range(args.warmup):
+        sim.run_one()
+    sim.sync()
+    sim.reset_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.run_one()
+    sim.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: the solver sweep, HIP events on the solver's own stream over the timed region
+    sweep_ms, sweep_n = sim.timing("sweep")
+    fam = {k: sim.timing(k) for k in ("sweep", "divergence", "gradient", "advect", "misc", "comm")}
+    local_cells = W * H * sim.local_depth
+    elem = 8 if args.precision == "fp64" else 4
+    bytes_per_launch = SWEEP_BYTES_PER_CELL * (elem // 4) * local_cells
+    avg_ms = sweep_ms / max(1, sweep_n)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if sweep_n else 0.0
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "sweep_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f).get(name, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "cells_steps_per_sec",
+        "value": cells * args.steps / elapsed,
+        "unit": "cells*steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if args.precision == "fp64" else "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %dx%dx%d wind tunnel, %s, %d solver iterations per solve, Jacobi, dumps off"
+                        % (name, W, H, D, "sphere + plate STL obstacles" if cfg["plate"] else "sphere STL obstacle", acc),
+            "grid": [W, H, D], "acc": acc, "solver": "jacobi",
+            "parallelism": "z-slabs x%d, RCCL halo exchange" % world if world > 1 else "single GPU",
+            "voxelizer_points_added": added,
+        },
+        "jacobi_iter_per_sec": 1e3 / avg_ms if sweep_n else None,
+        "roofline": {
+            "kernel": "jacobi_sweep_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches": sweep_n,
+        },
+        "kernel_ms": {k: {"total_ms": v[0], "launches": v[1]} for k, v in fam.items()},
+        "step_bytes_per_cell_algorithmic": 208 + 72 * acc,
+        "step_roofline_frac": (208 + 72 * acc) * (elem // 4) * cells * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+    }
+    sim.close()
+
+    if world == 1 and not args.no_extra and name == "c3":
+        # the other size the metric is quoted on: 256^3 (config 2), short run
+        c2 = WORKLOADS["c2"]
+        s2 = F.Simulation(c2["W"], c2["H"], c2["D"], 3, acc=c2["acc"], quiet=1, dump_every=0, profile=1)
+        with tempfile.TemporaryDirectory() as tmp:
+            add_obstacles(F, s2, c2, tmp)
+        s2.run_one()
+        s2.sync()
+        s2.reset_timing()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            s2.run_one()
+        s2.sync()
+        e2 = time.perf_counter() - t0
+        ms2, n2 = s2.timing("sweep")
+        out["extra_256"] = {
+            "workload": "c2: 256^3, sphere, 40 iterations",
+            "cells_steps_per_sec": 256 ** 3 * 5 / e2,
+            "jacobi_iter_per_sec": 1e3 / (ms2 / max(1, n2)),
+            "sweep_GBps_algorithmic": 12 * 256 ** 3 / (ms2 / max(1, n2) * 1e-3) / 1e9,
+        }
+        s2.close()
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(acc)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
