@@ -738,6 +738,16 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         s->profile = (v != "0");
     } else if (k == "elide_dead_density_solve") {
         s->elide_dead = (v != "0");
+    } else if (k == "sweep_ry") {
+        int r = atoi(value);
+        if (r != 2 && r != 4 && r != 8) return fail(FS_EINVAL, "sweep_ry: 2 | 4 | 8");
+        fs::sweep_tune().ry = r;
+    } else if (k == "sweep_zc") {
+        fs::sweep_tune().zc_len = atoi(value);
+    } else if (k == "sweep_blocks") {
+        fs::sweep_tune().target_blocks = atoi(value) > 0 ? atoi(value) : 2048;
+    } else if (k == "sweep_abl") {
+        fs::sweep_tune().abl = atoi(value);
     } else {
         return fail(FS_EINVAL, "unknown option '%s'", key);
     }

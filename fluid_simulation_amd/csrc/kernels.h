@@ -34,6 +34,16 @@ struct SlabCtx {
     int hi_wall;    // 1 if local plane D+1 is the physical z=Dglobal+1 ghost plane
 };
 
+// Tunables of the sweep launch (set through fs_set_option "sweep_ry" / "sweep_zc" /
+// "sweep_blocks"; "sweep_abl" selects timing-only ablation builds used by tools/tune_sweep.py).
+struct SweepTune {
+    int ry = 4;               // rows per wave patch: 2, 4 or 8
+    int zc_len = 0;           // planes per z chunk; 0 = derive from target_blocks
+    int target_blocks = 2048; // aim for about this many workgroups per launch
+    int abl = 0;
+};
+SweepTune& sweep_tune();
+
 template <class T>
 void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
                    const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last);

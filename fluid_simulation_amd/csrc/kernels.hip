@@ -44,7 +44,21 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblk)
 // L1/L2 hits).  x neighbours cross lanes with a wave shuffle; only the wave's edge lanes
 // touch memory for them.  A block is four waves stacked in y.
 // =====================================================================================
+// Everything a wave needs of one z plane when that plane is the stencil centre: its own
+// RY x 4 patch, the rows above and below the patch, and the two columns beside it.
 template <class T, int RY>
+struct PlaneIn {
+    T core[RY][4];
+    T hb[4], ht[4];      // rows y0-1 and y0+RY
+    T eL[RY], eR[RY];    // columns x0-1 and x0+4 (only the wave's edge lanes load them)
+};
+template <class T, int RY>
+struct AuxIn {
+    T rhs[RY][4];
+    unsigned fl[RY];     // four flag bytes per row
+};
+
+template <class T, int RY, int ABL>
 __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                             const T* __restrict__ rhs, T* __restrict__ dst,
                                                             const uint8_t* __restrict__ flags, int b, T a, T inv_c,
@@ -66,105 +80,156 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
     const int zend = min(z_last, zbeg + zc_len - 1);
     if (zbeg > zend) return;
 
-    const bool edge_l = (lane == 0);                     // left neighbour of element 0 comes from memory
-    const bool edge_r = (lane == 63) || (x0 + 4 > W);    // right neighbour of element 3 comes from memory
     const bool full_group = (x0 + 3 <= W);
+    const bool edge_l = lane_on && (lane == 0);                                   // x0-1 comes from memory
+    const bool edge_r = lane_on && full_group && ((lane == 63) || (x0 + 4 > W));  // x0+4 comes from memory
     const unsigned zero_bits = (b == 0) ? F_SOLID : (F_SOLID | F_NEAR);
     const T zero = (T)0;
+    const long row0 = cell(g, x0, y0, 0);                // lane's first cell in plane 0
 
-    T m[RY][4], c[RY][4], p[RY][4];
-
-    auto load_rows = [&](const T* arr, int z, T (&out)[RY][4], int ymax) {
+    auto ld4 = [&](const T* ptr, bool on, T (&out)[4]) {
+        V4<T> q = {{zero, zero, zero, zero}};
+        if (on) q = *reinterpret_cast<const V4<T>*>(ptr);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = q.e[e];
+    };
+    // rows up to the ghost row H+1 are fetched: in a partial band it is some row's y+1 neighbour
+    auto fetch_core = [&](int z, T (&out)[RY][4]) {
+        const T* pz = src + row0 + (long)z * g.sz;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) ld4(pz + r * g.sy, lane_on && (y0 + r <= H + 1), out[r]);
+    };
+    auto fetch_plane = [&](int z, PlaneIn<T, RY>& P, bool as_centre) {
+        fetch_core(z, P.core);
+        const T* pz = src + row0 + (long)z * g.sz;
+        const bool halo = as_centre && !(ABL & 2);
+        ld4(pz - g.sy, lane_on && halo, P.hb);
+        ld4(pz + RY * g.sy, lane_on && halo && (y0 + RY <= H + 1), P.ht);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            int y = y0 + r;
-            if (lane_on && y <= ymax) {
-                V4<T> q = *reinterpret_cast<const V4<T>*>(arr + cell(g, x0, y, z));
+            const bool row_on = as_centre && (y0 + r <= H);
+            P.eL[r] = (edge_l && row_on) ? pz[r * g.sy - 1] : zero;
+            P.eR[r] = (edge_r && row_on) ? pz[r * g.sy + 4] : zero;
+        }
+    };
+    auto fetch_aux = [&](int z, AuxIn<T, RY>& X) {
+        const long off = row0 + (long)z * g.sz;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) out[r][e] = q.e[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out[r][e] = zero;
-            }
+        for (int r = 0; r < RY; ++r) {
+            const bool on = lane_on && (y0 + r <= H);
+            ld4(rhs + off + r * g.sy, on && !(ABL & 4), X.rhs[r]);
+            X.fl[r] = (on && !(ABL & 1)) ? *reinterpret_cast<const unsigned*>(flags + off + r * g.sy) : 0u;
         }
     };
 
-    load_rows(src, zbeg - 1, m, H + 1);
-    load_rows(src, zbeg, c, H + 1);
+    // Software pipeline: while plane z is computed, the loads of plane z+2 (and of the rhs /
+    // flags of plane z+1) are in flight, so a wave waits for memory once per plane instead of
+    // once per dependent load.
+    T m[RY][4];
+    PlaneIn<T, RY> A, B, N;
+    AuxIn<T, RY> xa, xn;
+    fetch_core(zbeg - 1, m);
+    fetch_plane(zbeg, A, true);
+    fetch_aux(zbeg, xa);
+    fetch_plane(zbeg + 1, B, zbeg + 1 <= zend);
 
     for (int z = zbeg; z <= zend; ++z) {
-        load_rows(src, z + 1, p, H + 1);
-        T rv[RY][4];
-        load_rows(rhs, z, rv, H);
-
-        // in-plane halo of the centre plane
-        T hb[4], ht[4];
-        {
-            V4<T> q = {{zero, zero, zero, zero}};
-            if (lane_on) q = *reinterpret_cast<const V4<T>*>(src + cell(g, x0, y0 - 1, z));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hb[e] = q.e[e];
-            V4<T> t = {{zero, zero, zero, zero}};
-            if (lane_on && y0 + RY <= H + 1) t = *reinterpret_cast<const V4<T>*>(src + cell(g, x0, y0 + RY, z));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ht[e] = t.e[e];
+        if (z + 1 <= zend) {                              // wave-uniform
+            fetch_plane(z + 2, N, z + 2 <= zend);
+            fetch_aux(z + 1, xn);
         }
 
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
             const int y = y0 + r;
-            const bool row_on = (y <= H);                // wave-uniform
             // x neighbours across lanes (all lanes execute the shuffles)
-            T left = __shfl_up(c[r][3], 1);
-            T right = __shfl_down(c[r][0], 1);
-            if (row_on && lane_on) {
-                const long base = cell(g, x0, y, z);
-                if (edge_l) left = src[base - 1];
-                if (edge_r && full_group) right = src[base + 4];
-                const unsigned fl = *reinterpret_cast<const unsigned*>(flags + base);
-
+            T left = __shfl_up(A.core[r][3], 1);
+            T right = __shfl_down(A.core[r][0], 1);
+            if (edge_l) left = A.eL[r];
+            if (edge_r) right = A.eR[r];
+            if (y <= H && lane_on) {                      // y <= H is wave-uniform
+                const long base = row0 + (long)z * g.sz + r * g.sy;
+                const unsigned fl = xa.fl[r];
                 T u[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    T xp1 = (e < 3) ? c[r][e + 1] : right;
-                    T xm1 = (e > 0) ? c[r][e - 1] : left;
-                    T yp1 = (r < RY - 1) ? c[r + 1][e] : ht[e];
-                    T ym1 = (r > 0) ? c[r - 1][e] : hb[e];
+                    T xp1 = (e < 3) ? A.core[r][e + 1] : right;
+                    T xm1 = (e > 0) ? A.core[r][e - 1] : left;
+                    T yp1 = (r < RY - 1) ? A.core[r + 1][e] : A.ht[e];
+                    T ym1 = (r > 0) ? A.core[r - 1][e] : A.hb[e];
                     // simulation.cpp:264-269: order x+1, x-1, y+1, y-1, z+1, z-1
-                    T nb = xp1 + xm1 + yp1 + ym1 + p[r][e] + m[r][e];
-                    u[e] = (rv[r][e] + a * nb) * inv_c;
+                    T nb = xp1 + xm1 + yp1 + ym1 + B.core[r][e] + m[r][e];
+                    u[e] = (xa.rhs[r][e] + a * nb) * inv_c;
                 }
 
                 // ---- fused setBounds on the new iterate (faces read un-zeroed values) ----
-                V4<T> st, gy, gz;
+                V4<T> st;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int x = x0 + e;
-                    const bool in = (x <= W);
                     const bool kill = ((fl >> (8 * e)) & zero_bits) != 0;
                     T ghost_src = (e > 0) ? u[e - 1] : zero;
-                    st.e[e] = in ? (kill ? zero : u[e]) : ((x == W + 1) ? ghost_src : zero);   // outflow ghost, :191
-                    gy.e[e] = in ? ((b == 2) ? -u[e] : u[e]) : zero;                            // :198-201
-                    gz.e[e] = in ? ((b == 3) ? -u[e] : u[e]) : zero;                            // :208-214
+                    // cells past W: the outflow ghost copies u(W) (:191); row padding stays 0
+                    st.e[e] = (x <= W) ? (kill ? zero : u[e]) : ((x == W + 1) ? ghost_src : zero);
                 }
-                *reinterpret_cast<V4<T>*>(dst + base) = st;
+                if (!(ABL & 8) || st.e[0] == (T)123456789) *reinterpret_cast<V4<T>*>(dst + base) = st;
                 if (x0 == 1) dst[base - 1] = (b == 1) ? -u[0] : u[0];                            // :189-190
                 if (full_group && x0 + 3 == W) dst[base + 4] = u[3];                            // :191
-                if (y == 1) *reinterpret_cast<V4<T>*>(dst + base - g.sy) = gy;
-                if (y == H) *reinterpret_cast<V4<T>*>(dst + base + g.sy) = gy;
-                if (z == 1 && sc.lo_wall) *reinterpret_cast<V4<T>*>(dst + base - g.sz) = gz;
-                if (z == D && sc.hi_wall) *reinterpret_cast<V4<T>*>(dst + base + g.sz) = gz;
+                const bool yface = (y == 1) || (y == H);                                        // wave-uniform
+                const bool zface = (z == 1 && sc.lo_wall) || (z == D && sc.hi_wall);            // wave-uniform
+                if (yface || zface) {
+                    V4<T> gy, gz;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool in = (x0 + e <= W);
+                        gy.e[e] = in ? ((b == 2) ? -u[e] : u[e]) : zero;                        // :198-201
+                        gz.e[e] = in ? ((b == 3) ? -u[e] : u[e]) : zero;                        // :208-214
+                    }
+                    if (y == 1) *reinterpret_cast<V4<T>*>(dst + base - g.sy) = gy;
+                    if (y == H) *reinterpret_cast<V4<T>*>(dst + base + g.sy) = gy;
+                    if (z == 1 && sc.lo_wall) *reinterpret_cast<V4<T>*>(dst + base - g.sz) = gz;
+                    if (z == D && sc.hi_wall) *reinterpret_cast<V4<T>*>(dst + base + g.sz) = gz;
+                }
             }
         }
 
 #pragma unroll
         for (int r = 0; r < RY; ++r)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                m[r][e] = c[r][e];
-                c[r][e] = p[r][e];
-            }
+            for (int e = 0; e < 4; ++e) m[r][e] = A.core[r][e];
+        A = B;
+        B = N;
+        xa = xn;
     }
+}
+
+SweepTune& sweep_tune()
+{
+    static SweepTune t;
+    return t;
+}
+
+template <class T, int RY, int ABL>
+static void launch_jacobi_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
+                            const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last)
+{
+    const SweepTune& tune = sweep_tune();
+    const int nxw = (g.W + 255) / 256;
+    const int nyb = (g.H + RY - 1) / RY;
+    const int nybg = (nyb + 3) / 4;
+    const int planes = z_last - z_first + 1;
+    // enough z chunks for ~target_blocks blocks, but chunks of at least 8 planes (each chunk
+    // re-reads 2 warm-up planes)
+    const long per_layer = (long)nxw * nybg;
+    long want = (tune.target_blocks + per_layer - 1) / per_layer;
+    if (want < 1) want = 1;
+    int zc_len = (int)((planes + want - 1) / want);
+    if (zc_len < 8) zc_len = planes < 8 ? planes : 8;
+    if (tune.zc_len > 0) zc_len = tune.zc_len < planes ? tune.zc_len : planes;
+    const int nzc = (planes + zc_len - 1) / zc_len;
+    const int nblk = (int)(per_layer * nzc);
+    hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY, ABL>), dim3(nblk), dim3(256), 0, st, g, sc, src, rhs, dst, flags, b,
+                       a, inv_c, z_first, z_last, zc_len, nxw, nybg, nblk);
 }
 
 template <class T>
@@ -172,22 +237,23 @@ void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T
                    const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last)
 {
     if (z_last < z_first) return;
-    constexpr int RY = 4;
-    const int nxw = (g.W + 255) / 256;
-    const int nyb = (g.H + RY - 1) / RY;
-    const int nybg = (nyb + 3) / 4;
-    const int planes = z_last - z_first + 1;
-    // enough z chunks for >= ~2048 blocks, but chunks of at least 8 planes (2-plane warm-up each)
-    int zc_len = planes;
-    const long per_layer = (long)nxw * nybg;
-    long want = (2048 + per_layer - 1) / per_layer;
-    if (want < 1) want = 1;
-    zc_len = (int)((planes + want - 1) / want);
-    if (zc_len < 8) zc_len = planes < 8 ? planes : 8;
-    const int nzc = (planes + zc_len - 1) / zc_len;
-    const int nblk = (int)(per_layer * nzc);
-    hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY>), dim3(nblk), dim3(256), 0, st, g, sc, src, rhs, dst, flags, b, a,
-                       inv_c, z_first, z_last, zc_len, nxw, nybg, nblk);
+    const SweepTune& tune = sweep_tune();
+#define FS_GO(RY, ABL) launch_jacobi_v<T, RY, ABL>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last)
+    if (tune.abl == 0) {
+        if (tune.ry == 2) FS_GO(2, 0);
+        else if (tune.ry == 8) FS_GO(8, 0);
+        else FS_GO(4, 0);
+    } else {   // timing-only ablations (wrong results by design), RY = 4
+        switch (tune.abl) {
+            case 1: FS_GO(4, 1); break;
+            case 2: FS_GO(4, 2); break;
+            case 4: FS_GO(4, 4); break;
+            case 8: FS_GO(4, 8); break;
+            case 3: FS_GO(4, 3); break;
+            default: FS_GO(4, 0); break;
+        }
+    }
+#undef FS_GO
 }
 template void launch_jacobi<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, const float*, float*,
                                    const uint8_t*, int, float, float, int, int);
