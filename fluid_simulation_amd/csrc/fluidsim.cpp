@@ -43,8 +43,8 @@ int fail(int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail(FS_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-enum Family { FAM_SWEEP = 0, FAM_DIV, FAM_GRAD, FAM_ADVECT, FAM_BOUNDS, FAM_MISC, FAM_COMM, FAM_COUNT };
-const char* const kFamilyNames[FAM_COUNT] = { "sweep", "divergence", "gradient", "advect", "bounds", "misc", "comm" };
+enum Family { FAM_SWEEP = 0, FAM_PAIR, FAM_DIV, FAM_GRAD, FAM_ADVECT, FAM_BOUNDS, FAM_MISC, FAM_COMM, FAM_COUNT };
+const char* const kFamilyNames[FAM_COUNT] = { "sweep", "sweep_pair", "divergence", "gradient", "advect", "bounds", "misc", "comm" };
 
 constexpr int NPOOL = FS_NFIELDS + 3;   // named fields + ping-pong scratch
 
@@ -286,10 +286,16 @@ struct Engine : EngineBase {
         }
         int src = cur;
         bool src_temp = false;
+        const bool pairs = fs::pair_supported<T>(g, sc);
         for (int it = 0; it < sweeps; ++it) {
             int dst = acquire(src, rhs);
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
-            {
+            if (pairs && it + 1 < sweeps) {
+                // two sweeps per pass over memory; timed as its own family, one launch each
+                ScopedSpan sp(S, FAM_PAIR);
+                fs::launch_jacobi_pair<T>(S->stream, g, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c);
+                ++it;
+            } else {
                 ScopedSpan sp(S, FAM_SWEEP);
                 fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c, 1, g.D);
             }
@@ -621,8 +627,14 @@ struct Engine : EngineBase {
         fs::launch_jacobi<T>(S->stream, g, sc, arr[slot[field]], arr[slot[prev]], arr[s1], flags, b, (T)a, inv_c, 1, g.D);
         HIP_TRY(hipEventRecord(e0, S->stream));
         int src = s1, dst = s2;
+        const bool pairs = fs::pair_supported<T>(g, sc);
         for (int r = 0; r < reps; ++r) {
-            fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c, 1, g.D);
+            if (pairs && r + 1 < reps) {
+                fs::launch_jacobi_pair<T>(S->stream, g, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c);
+                ++r;
+            } else {
+                fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c, 1, g.D);
+            }
             int t = src; src = dst; dst = t;
         }
         HIP_TRY(hipEventRecord(e1, S->stream));
@@ -748,6 +760,14 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         fs::sweep_tune().target_blocks = atoi(value) > 0 ? atoi(value) : 2048;
     } else if (k == "sweep_abl") {
         fs::sweep_tune().abl = atoi(value);
+    } else if (k == "sweep_fuse") {
+        int f = atoi(value);
+        if (f != 1 && f != 2) return fail(FS_EINVAL, "sweep_fuse: 1 | 2");
+        fs::sweep_tune().fuse = f;
+    } else if (k == "pair_zc") {
+        fs::sweep_tune().pair_zc = atoi(value);
+    } else if (k == "pair_small") {
+        fs::sweep_tune().pair_small = atoi(value);
     } else {
         return fail(FS_EINVAL, "unknown option '%s'", key);
     }

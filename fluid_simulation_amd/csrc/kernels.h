@@ -41,12 +41,23 @@ struct SweepTune {
     int zc_len = 0;           // planes per z chunk; 0 = derive from target_blocks
     int target_blocks = 2048; // aim for about this many workgroups per launch
     int abl = 0;
+    int fuse = 2;             // sweeps fused per pass over memory (1 = never fuse, 2 = pair kernel)
+    int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic
+    int pair_small = 0;       // pair-kernel workgroup shape: 0 = 12 waves (default), 1 = 8 waves, 3 = 16 waves
 };
 SweepTune& sweep_tune();
 
 template <class T>
 void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
                    const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last);
+
+// Two sweeps in one pass (temporal blocking); same result as two launch_jacobi calls.
+// Only for a slab that holds both physical z walls (single GPU) and W <= 1024.
+template <class T>
+bool pair_supported(const GridDesc& g, const SlabCtx& sc);
+template <class T>
+void launch_jacobi_pair(hipStream_t st, const GridDesc& g, const T* src, const T* rhs, T* dst, const uint8_t* flags,
+                        int b, T a, T inv_c);
 
 template <class T>
 void launch_gs_lex(hipStream_t st, const GridDesc& g, T* q, const T* rhs, const uint8_t* flags, int b, T a, T inv_c,

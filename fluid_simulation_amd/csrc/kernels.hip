@@ -261,6 +261,309 @@ template void launch_jacobi<double>(hipStream_t, const GridDesc&, const SlabCtx&
                                     const uint8_t*, int, double, double, int, int);
 
 // =====================================================================================
+// Two Jacobi sweeps per pass over memory (temporal blocking), bit-identical with two
+// launches of jacobi_sweep_kernel.
+//
+// One sweep moves 12 B per cell for 8 flops; the only way past the HBM roof is to apply
+// several sweeps while the data is on chip.  Level 0 = `src`, level 1 = the iterate after
+// one sweep + setBounds (never written to memory), level 2 = `dst`.
+//
+// A workgroup owns the full row width (NXW waves of 256 cells) times a band of BY = NYW*2
+// rows and marches along z.  Per plane zl it (1) computes level 1 of plane zl for its band
+// from level-0 planes zl-1..zl+1 held in registers, exactly as the single sweep does,
+// including the zeroing of solids and the ghost faces of setBounds; (2) publishes that
+// level-1 plane tile (interior rows + the ghost rows/columns setBounds would have written)
+// in LDS; (3) after one barrier computes level 2 of plane zl-1 from level-1 planes
+// zl-2, zl-1, zl of its own cells (registers) and the in-plane neighbours out of the LDS
+// tile, and stores it with the fused setBounds.  Three LDS plane buffers rotate, so one
+// barrier per plane suffices.  Bands overlap by two rows and z chunks by two planes: the
+// first and last level-1 row of a band have no level-2 output there (their level-1
+// neighbour row belongs to the next band); rows next to the walls use the ghost rows.
+// =====================================================================================
+template <class T, int NXW, int NYW>
+__global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, const T* __restrict__ src,
+                                                                     const T* __restrict__ rhs, T* __restrict__ dst,
+                                                                     const uint8_t* __restrict__ flags, int b, T a,
+                                                                     T inv_c, int zc_len, int nbands, int nblk)
+{
+    constexpr int RY = 2, BY = NYW * RY, TW = NXW * 256 + 8;
+    // ring of four level-1 plane tiles (plane z lives in slot z & 3); column index = x + 3
+    __shared__ T tile[4][BY][TW];
+
+    const int v = xcd_contiguous(blockIdx.x, nblk);
+    const int band = v % nbands, zc = v / nbands;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wx = wave % NXW, wy = wave / NXW;
+    const int W = g.W, H = g.H, D = g.D;
+    const int s = band * (BY - 2);                       // tile row t <-> grid row s + t
+    const int ty0 = wy * RY, y0 = s + ty0;
+    const int x0 = 1 + wx * 256 + lane * 4;
+    const bool lane_on = x0 <= W;
+    const int zbeg = 1 + zc * zc_len, zend = min(D, zbeg + zc_len - 1);   // level-2 output planes
+    if (zbeg > zend) return;                             // block-uniform
+    const int zl_first = max(1, zbeg - 1), zl_last = min(D, zend + 1);    // level-1 planes
+    const int out_lo = max(1, s + 1), out_hi = min(H, s + BY - 2);        // level-2 output rows
+
+    const bool full_group = (x0 + 3 <= W);
+    const bool edge_l = lane_on && (lane == 0);
+    const bool edge_r = lane_on && full_group && ((lane == 63) || (x0 + 4 > W));
+    const unsigned zero_bits = (b == 0) ? F_SOLID : (F_SOLID | F_NEAR);
+    const T zero = (T)0;
+    const long row0 = cell(g, x0, y0, 0);
+
+    auto ld4 = [&](const T* ptr, bool on, T (&out)[4]) {
+        V4<T> q = {{zero, zero, zero, zero}};
+        if (on) q = *reinterpret_cast<const V4<T>*>(ptr);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = q.e[e];
+    };
+    auto row_in_mem = [&](int y) { return y >= 0 && y <= H + 1; };
+    auto fetch_core = [&](int z, T (&out)[RY][4]) {
+        const T* pz = src + row0 + (long)z * g.sz;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) ld4(pz + r * g.sy, lane_on && row_in_mem(y0 + r), out[r]);
+    };
+    auto fetch_plane = [&](int z, PlaneIn<T, RY>& P) {
+        fetch_core(z, P.core);
+        const T* pz = src + row0 + (long)z * g.sz;
+        ld4(pz - g.sy, lane_on && row_in_mem(y0 - 1), P.hb);
+        ld4(pz + RY * g.sy, lane_on && row_in_mem(y0 + RY), P.ht);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const bool row_on = (y0 + r >= 1) && (y0 + r <= H);
+            P.eL[r] = (edge_l && row_on) ? pz[r * g.sy - 1] : zero;
+            P.eR[r] = (edge_r && row_on) ? pz[r * g.sy + 4] : zero;
+        }
+    };
+    auto fetch_aux = [&](int z, AuxIn<T, RY>& X) {
+        const long off = row0 + (long)z * g.sz;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const bool on = lane_on && (y0 + r >= 1) && (y0 + r <= H);
+            ld4(rhs + off + r * g.sy, on, X.rhs[r]);
+            X.fl[r] = on ? *reinterpret_cast<const unsigned*>(flags + off + r * g.sy) : 0u;
+        }
+    };
+
+    // one stencil application; simulation.cpp:264-269 order x+1, x-1, y+1, y-1, z+1, z-1
+    auto relax4 = [&](const T (&cc)[4], T left, T right, const T (&ym)[4], const T (&yp)[4], const T (&zm)[4],
+                      const T (&zp)[4], const T (&rh)[4], T (&u)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            T xp1 = (e < 3) ? cc[e + 1] : right;
+            T xm1 = (e > 0) ? cc[e - 1] : left;
+            T nb = xp1 + xm1 + yp[e] + ym[e] + zp[e] + zm[e];
+            u[e] = (rh[e] + a * nb) * inv_c;
+        }
+    };
+    // what setBounds leaves in memory for the lane's four cells of an interior row
+    auto settle4 = [&](const T (&u)[4], unsigned fl, T (&st)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int x = x0 + e;
+            const bool kill = ((fl >> (8 * e)) & zero_bits) != 0;
+            T ghost_src = (e > 0) ? u[e - 1] : zero;
+            st[e] = (x <= W) ? (kill ? zero : u[e]) : ((x == W + 1) ? ghost_src : zero);
+        }
+    };
+    auto face4 = [&](const T (&u)[4], bool negate, T (&out)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = (x0 + e <= W) ? (negate ? -u[e] : u[e]) : zero;
+    };
+    auto lds_row = [&](int z, int t, T (&out)[4]) {
+        V4<T> q = *reinterpret_cast<const V4<T>*>(&tile[z & 3][t][x0 + 3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = q.e[e];
+    };
+    auto lds_put = [&](int z, int t, const T (&in)[4]) {
+        V4<T> q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q.e[e] = in[e];
+        *reinterpret_cast<V4<T>*>(&tile[z & 3][t][x0 + 3]) = q;
+    };
+
+    // level 2 of plane zo: every level-1 operand comes out of the LDS ring (planes zo-1, zo,
+    // zo+1), x neighbours of the lane's own group by wave shuffle
+    auto level2 = [&](int zo, const AuxIn<T, RY>& X) {
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const int y = y0 + r, t = ty0 + r;
+            const bool row_out = (y >= out_lo) && (y <= out_hi);     // wave-uniform
+            T cc[4] = {zero, zero, zero, zero};
+            if (row_out && lane_on) lds_row(zo, t, cc);
+            T left = __shfl_up(cc[3], 1);
+            T right = __shfl_down(cc[0], 1);
+            if (!(row_out && lane_on)) continue;
+            if (edge_l) left = tile[zo & 3][t][x0 + 2];
+            if (edge_r) right = tile[zo & 3][t][x0 + 7];
+            T ym[4], yp[4], zm[4], zp[4];
+            lds_row(zo, t - 1, ym);
+            lds_row(zo, t + 1, yp);
+            lds_row(zo - 1, t, zm);
+            lds_row(zo + 1, t, zp);
+            T u[4], st[4];
+            relax4(cc, left, right, ym, yp, zm, zp, X.rhs[r], u);
+            settle4(u, X.fl[r], st);
+            const long base = row0 + (long)zo * g.sz + r * g.sy;
+            V4<T> q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q.e[e] = st[e];
+            *reinterpret_cast<V4<T>*>(dst + base) = q;
+            if (x0 == 1) dst[base - 1] = (b == 1) ? -u[0] : u[0];                               // :189-190
+            if (full_group && x0 + 3 == W) dst[base + 4] = u[3];                               // :191
+            if (y == 1 || y == H || zo == 1 || zo == D) {
+                T f[4];
+                V4<T> qq;
+                face4(u, b == 2, f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qq.e[e] = f[e];
+                if (y == 1) *reinterpret_cast<V4<T>*>(dst + base - g.sy) = qq;                  // :198-201
+                if (y == H) *reinterpret_cast<V4<T>*>(dst + base + g.sy) = qq;
+                face4(u, b == 3, f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qq.e[e] = f[e];
+                if (zo == 1) *reinterpret_cast<V4<T>*>(dst + base - g.sz) = qq;                 // :208-214
+                if (zo == D) *reinterpret_cast<V4<T>*>(dst + base + g.sz) = qq;
+            }
+        }
+    };
+
+    // level-0 stream, software-pipelined one plane ahead of its use (see jacobi_sweep_kernel)
+    T m[RY][4];
+    PlaneIn<T, RY> A, B, N;
+    AuxIn<T, RY> xc, xn, xm;
+    fetch_core(zl_first - 1, m);
+    fetch_plane(zl_first, A);
+    fetch_aux(zl_first, xc);
+    fetch_plane(zl_first + 1, B);
+    xm = xc;
+
+    for (int zl = zl_first; zl <= zl_last; ++zl) {
+        if (zl + 1 <= zl_last) {                         // block-uniform
+            fetch_plane(zl + 2, N);                      // zl+2 <= D+1
+            fetch_aux(zl + 1, xn);
+        }
+
+        // ---- level 1 of plane zl for this wave's rows, published with its setBounds ghosts
+        T gz[RY][4];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const int y = y0 + r, t = ty0 + r;
+            T left = __shfl_up(A.core[r][3], 1);
+            T right = __shfl_down(A.core[r][0], 1);
+            if (edge_l) left = A.eL[r];
+            if (edge_r) right = A.eR[r];
+            T u[4] = {zero, zero, zero, zero};
+            const bool row_on = (y >= 1) && (y <= H);    // wave-uniform
+            if (row_on && lane_on) {
+                T ym[4], yp[4], st[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ym[e] = (r > 0) ? A.core[r > 0 ? r - 1 : 0][e] : A.hb[e];
+                    yp[e] = (r < RY - 1) ? A.core[r < RY - 1 ? r + 1 : r][e] : A.ht[e];
+                }
+                relax4(A.core[r], left, right, ym, yp, m[r], B.core[r], xc.rhs[r], u);
+                settle4(u, xc.fl[r], st);
+                lds_put(zl, t, st);
+                if (x0 == 1) tile[zl & 3][t][3] = (b == 1) ? -u[0] : u[0];                      // ghost column x = 0
+                if (full_group && x0 + 3 == W) tile[zl & 3][t][W + 4] = u[3];                  // ghost column x = W+1
+                T f[4];
+                if (y == 1 && t >= 1) { face4(u, b == 2, f); lds_put(zl, t - 1, f); }           // ghost row y = 0
+                if (y == H && t + 1 < BY) { face4(u, b == 2, f); lds_put(zl, t + 1, f); }       // ghost row y = H+1
+            }
+            face4(u, b == 3, gz[r]);
+        }
+        if (zl == 1) {                                   // level-1 ghost plane z = 0 (:208-210)
+#pragma unroll
+            for (int r = 0; r < RY; ++r)
+                if (lane_on && y0 + r >= 1 && y0 + r <= H) lds_put(0, ty0 + r, gz[r]);
+        }
+        __syncthreads();
+
+        // ---- level 2 of plane zl-1
+        if (zl - 1 >= zbeg) level2(zl - 1, xm);
+        if (zl == D && zend == D) {
+            // top wall: level-1 ghost plane z = D+1 is +-u1(D) (:212-214).  Its ring slot still
+            // holds plane D-3, which slower waves may be reading: fence both sides.
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RY; ++r)
+                if (lane_on && y0 + r >= 1 && y0 + r <= H) lds_put(D + 1, ty0 + r, gz[r]);
+            __syncthreads();
+            level2(D, xc);
+        }
+
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[r][e] = A.core[r][e];
+        A = B;
+        B = N;
+        xm = xc;
+        xc = xn;
+    }
+}
+
+template <class T, int NXW, int NYW>
+static void launch_pair_v(hipStream_t st, const GridDesc& g, const T* src, const T* rhs, T* dst, const uint8_t* flags,
+                          int b, T a, T inv_c)
+{
+    constexpr int BY = NYW * 2;
+    const SweepTune& tune = sweep_tune();
+    const int nbands = (g.H + (BY - 2) - 1) / (BY - 2);
+    // z chunks: each re-reads 4 level-0 planes and recomputes 2 level-1 planes, so keep them
+    // long; pick the count that fills the CUs most evenly (one or two blocks per CU)
+    int best_nzc = 1;
+    double best = -1.0;
+    const int slots = 256;   // one workgroup per CU (VGPR-limited)
+    for (int nzc = 1; nzc <= 64 && g.D / nzc >= 12; ++nzc) {
+        const long blocks = (long)nbands * nzc;
+        const long rounds = (blocks + slots - 1) / slots;
+        const int len = (g.D + nzc - 1) / nzc;
+        const double eff = (double)blocks / (double)(rounds * slots) * (double)len / (double)(len + 3);
+        if (eff > best + 1e-9) { best = eff; best_nzc = nzc; }
+    }
+    int zc_len = (g.D + best_nzc - 1) / best_nzc;
+    if (tune.pair_zc > 0) zc_len = tune.pair_zc < g.D ? tune.pair_zc : g.D;
+    const int nzc = (g.D + zc_len - 1) / zc_len;
+    const int nblk = nbands * nzc;
+    hipLaunchKernelGGL((jacobi_pair_kernel<T, NXW, NYW>), dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, src, rhs, dst,
+                       flags, b, a, inv_c, zc_len, nbands, nblk);
+}
+
+template <class T>
+bool pair_supported(const GridDesc& g, const SlabCtx& sc)
+{
+    return sc.lo_wall && sc.hi_wall && g.W <= 1024 && sweep_tune().fuse >= 2;
+}
+template bool pair_supported<float>(const GridDesc&, const SlabCtx&);
+template bool pair_supported<double>(const GridDesc&, const SlabCtx&);
+
+template <>
+void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const float* src, const float* rhs, float* dst,
+                               const uint8_t* flags, int b, float a, float inv_c)
+{
+    const int nxw = (g.W + 255) / 256;
+    const int shape = sweep_tune().pair_small;   // 0 = default (768 threads: 12 waves at <=168 VGPRs, one block per CU)
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, src, rhs, dst, flags, b, a, inv_c)
+    if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
+    else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
+    else if (nxw == 3) FS_PAIR(3, 4);
+    else FS_PAIR(4, 3);
+#undef FS_PAIR
+}
+template <>
+void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const double* src, const double* rhs, double* dst,
+                                const uint8_t* flags, int b, double a, double inv_c)
+{
+    const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, src, rhs, dst, flags, b, a, inv_c);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, src, rhs, dst, flags, b, a, inv_c);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, src, rhs, dst, flags, b, a, inv_c);
+    else launch_pair_v<double, 4, 2>(st, g, src, rhs, dst, flags, b, a, inv_c);
+}
+
+// =====================================================================================
 // Reference-order in-place sweep (verification mode, single GPU).
 //   linearSolver  simulation.cpp:251-273 at one thread: x outermost, z innermost, in place.
 // Cells on a hyperplane x+y+z = s only depend on hyperplanes s-1 (already updated) and s+1

@@ -144,8 +144,9 @@ int fs_field_stats(fs_sim* s, int which, double* sum, double* min, double* max);
 /* ---- measurement ---------------------------------------------------------------- */
 
 /* With option "profile"="1": accumulated HIP-event time and launch count of one kernel
- * family since the last fs_reset_timing: "sweep" "divergence" "gradient" "advect"
- * "bounds" "misc".  Events are recorded on the handle's own stream. */
+ * family since the last fs_reset_timing: "sweep" (one solver iteration per launch)
+ * "sweep_pair" (two iterations per launch) "divergence" "gradient" "advect" "bounds" "misc"
+ * "comm".  Events are recorded on the handle's own stream. */
 int fs_get_timing(fs_sim* s, const char* family, double* total_ms, long* launches);
 int fs_reset_timing(fs_sim* s);
 

@@ -125,8 +125,14 @@ class Oracle(_Sim):
         self.dtype = np.float64 if fp64 else np.float32
         super().__init__(lib, w, h, d, **kw)
         self._call("set_solver", C.c_int(solver))
-        if threads is not None:
-            lib.cr_set_threads(C.c_int(threads))
+        if threads is None:
+            # never the OpenMP default: a GPU box reports all 256 host cores but grants 16
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count() or 1
+            threads = max(1, min(threads, 8))
+        lib.cr_set_threads(C.c_int(threads))
 
     def load_stl(self, path, scale=0.8, rot=(0.0, 0.0, 0.0), translate=(0.0, 0.0, 0.0), seed=1):
         return self._call("load_stl", C.c_char_p(os.fsencode(path)), C.c_float(scale),

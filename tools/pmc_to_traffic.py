@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE output directories into per-launch HBM bytes of
+the solver kernels (development tool):  python tools/pmc_to_traffic.py <fetch_dir> <write_dir> <workload>
+
+gfx950 corrections (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): FETCH_SIZE and
+WRITE_SIZE are in units of 1024 B; FETCH_SIZE reports exactly half of the bytes of a wide
+(16 B/lane) coalesced streaming read, so it is doubled; WRITE_SIZE is exact."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+fetch_dir, write_dir, workload = sys.argv[1:4]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("jacobi_pair_kernel", "jacobi_sweep_kernel", "advect_kernel", "divergence_kernel", "gradient_kernel")
+
+
+def mean_by_kernel(d, counter):
+    acc = collections.defaultdict(list)
+    for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                for key in KEYS:
+                    if key in r["Kernel_Name"]:
+                        acc[key].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+f, nf = mean_by_kernel(fetch_dir, "FETCH_SIZE")
+w, nw = mean_by_kernel(write_dir, "WRITE_SIZE")
+out_path = os.path.join(root, "profiles", "sweep_traffic.json")
+data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+data.setdefault(workload, {})
+for k in sorted(set(f) | set(w)):
+    rd = 2.0 * f.get(k, 0.0) * 1024.0
+    wr = w.get(k, 0.0) * 1024.0
+    data[workload][k] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+                         "FETCH_SIZE_raw_mean": f.get(k), "WRITE_SIZE_raw_mean": w.get(k),
+                         "dispatches_sampled": [nf.get(k, 0), nw.get(k, 0)],
+                         "correction": "read = 2 * FETCH_SIZE * 1024 (gfx950 half-count), write = WRITE_SIZE * 1024"}
+    print(k, "read %.1f MB write %.1f MB" % (rd / 1e6, wr / 1e6))
+json.dump(data, open(out_path, "w"), indent=1)
