@@ -14,7 +14,15 @@
 #include <rccl/rccl.h>   // types and enums only; no link-time dependency
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <cstring>
+#include <vector>
 #include <string>
 
 #include "kernels.h"
@@ -70,10 +78,93 @@ struct RcclApi {
     }
 };
 
+// Host-staged transport for development and tests: ranks are processes on one host (they may
+// even share one GPU, which RCCL refuses), planes travel through a POSIX shared-memory
+// segment with a sense-reversing barrier.  Fully synchronous and slow by design; it runs the
+// same slab kernels, flags, wall handling and exchange schedule as the RCCL transport, so a
+// 1-GPU box can verify that a z-slab run is bit-identical with the single-GPU run.
+// Selected by a unique id that starts with "FSSHM:" followed by the segment name.
+struct ShmTransport {
+    struct Header {
+        std::atomic<int> count;
+        std::atomic<int> generation;
+        std::atomic<int> ready;        // set by rank 0 once the segment is sized
+        size_t slot_bytes;             // capacity of one mailbox slot / one gathered plane
+        int gather_planes;
+    };
+    std::string name;
+    int rank = 0, nranks = 1;
+    Header* hdr = nullptr;
+    char* base = nullptr;
+    size_t total = 0;
+    std::vector<char> bounce;
+
+    static size_t layout(size_t slot, int nranks, int gplanes) { return 4096 + slot * ((size_t)2 * nranks + gplanes) + 4096; }
+    char* mailbox(int r, int side) { return base + 4096 + hdr->slot_bytes * ((size_t)2 * r + side); }
+    char* gather(int plane) { return base + 4096 + hdr->slot_bytes * ((size_t)2 * nranks + plane); }
+    double* stats(int r) { return reinterpret_cast<double*>(base + 4096 + hdr->slot_bytes * ((size_t)2 * nranks + hdr->gather_planes)) + 4 * r; }
+
+    // every rank calls this with the same sizes before the first exchange
+    int ensure(size_t slot_bytes, int gplanes, std::string* err)
+    {
+        if (base) return 0;
+        total = layout(slot_bytes, nranks, gplanes);
+        int fd = -1;
+        if (rank == 0) {
+            fd = shm_open(name.c_str(), O_CREAT | O_RDWR, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)total) != 0) { *err = "shm_open/ftruncate failed for " + name; return -1; }
+        } else {
+            for (int tries = 0; tries < 60000; ++tries) {
+                fd = shm_open(name.c_str(), O_RDWR, 0600);
+                struct stat sb;
+                if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= total) break;
+                if (fd >= 0) { close(fd); fd = -1; }
+                usleep(1000);
+            }
+            if (fd < 0) { *err = "timed out waiting for shared segment " + name; return -1; }
+        }
+        void* m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { *err = "mmap failed for " + name; return -1; }
+        base = static_cast<char*>(m);
+        hdr = reinterpret_cast<Header*>(base);
+        if (rank == 0) {
+            hdr->slot_bytes = slot_bytes;
+            hdr->gather_planes = gplanes;
+            hdr->ready.store(1, std::memory_order_release);
+        } else {
+            while (hdr->ready.load(std::memory_order_acquire) != 1) usleep(200);
+        }
+        barrier();
+        return 0;
+    }
+    void barrier()
+    {
+        const int gen = hdr->generation.load(std::memory_order_acquire);
+        if (hdr->count.fetch_add(1, std::memory_order_acq_rel) == nranks - 1) {
+            hdr->count.store(0, std::memory_order_relaxed);
+            hdr->generation.fetch_add(1, std::memory_order_acq_rel);
+        } else {
+            while (hdr->generation.load(std::memory_order_acquire) == gen) sched_yield();
+        }
+    }
+    void destroy()
+    {
+        if (base) {
+            barrier();
+            munmap(base, total);
+            if (rank == 0) shm_unlink(name.c_str());
+        }
+        base = nullptr;
+        hdr = nullptr;
+    }
+};
+
 struct Comm {
     int rank = 0, nranks = 1;
     ncclComm_t comm = nullptr;
     RcclApi* api = nullptr;
+    ShmTransport* shm = nullptr;
     std::string err;
 
     bool active() const { return nranks > 1; }
@@ -93,6 +184,16 @@ struct Comm {
 
     int init(int rank_, int nranks_, const void* id128)
     {
+        const char* idc = static_cast<const char*>(id128);
+        if (strncmp(idc, "FSSHM:", 6) == 0) {
+            shm = new ShmTransport;
+            shm->name = std::string(idc + 6, strnlen(idc + 6, 120));
+            shm->rank = rank_;
+            shm->nranks = nranks_;
+            rank = rank_;
+            nranks = nranks_;
+            return 0;
+        }
         RcclApi& a = RcclApi::get(&err);
         if (!a.lib) return -1;
         api = &a;
@@ -108,6 +209,7 @@ struct Comm {
     void destroy()
     {
         if (comm && api) api->CommDestroy(comm);
+        if (shm) { shm->destroy(); delete shm; shm = nullptr; }
         comm = nullptr;
         nranks = 1;
     }
@@ -117,15 +219,37 @@ struct Comm {
         ncclResult_t r_ = (call);                                             \
         if (r_ != ncclSuccess) { err = api->GetErrorString(r_); return -1; }  \
     } while (0)
+#define FS_HIPC(call)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) { err = hipGetErrorString(e_); return -1; }     \
+    } while (0)
+
+    int shm_ready(const GridDesc& g, int Dglobal)
+    {
+        // slots sized for fp64 planes so that one segment serves every field type
+        return shm->ensure((size_t)g.sz * 8, Dglobal + 2, &err);
+    }
 
     // Refresh local planes 0 and D+1 of `a` (LEAD-shifted pointer) from the neighbouring
     // slabs' planes D and 1.  Physical wall planes (rank 0 low side, last rank high side)
     // are left alone: the kernels write them.
-    int exchange_halo(hipStream_t st, void* a, const GridDesc& g, size_t elem)
+    int exchange_halo(hipStream_t st, void* a, const GridDesc& g, size_t elem, int Dglobal = 0)
     {
         if (!active()) return 0;
         char* base = static_cast<char*>(a);
         const size_t plane = (size_t)g.sz * elem;
+        if (shm) {
+            if (shm_ready(g, Dglobal ? Dglobal : g.D * nranks)) return -1;
+            FS_HIPC(hipStreamSynchronize(st));
+            if (rank > 0) FS_HIPC(hipMemcpy(shm->mailbox(rank - 1, 1), base + plane, plane, hipMemcpyDeviceToHost));
+            if (rank < nranks - 1) FS_HIPC(hipMemcpy(shm->mailbox(rank + 1, 0), base + (size_t)g.D * plane, plane, hipMemcpyDeviceToHost));
+            shm->barrier();
+            if (rank > 0) FS_HIPC(hipMemcpy(base, shm->mailbox(rank, 0), plane, hipMemcpyHostToDevice));
+            if (rank < nranks - 1) FS_HIPC(hipMemcpy(base + (size_t)(g.D + 1) * plane, shm->mailbox(rank, 1), plane, hipMemcpyHostToDevice));
+            shm->barrier();
+            return 0;
+        }
         FS_NCCL(api->GroupStart());
         if (rank > 0) {
             FS_NCCL(api->Send(base + 1 * plane, plane, ncclInt8, rank - 1, comm, st));
@@ -146,6 +270,21 @@ struct Comm {
         const char* s = static_cast<const char*>(src);
         char* d = static_cast<char*>(dst);
         const size_t plane = (size_t)g.sz * elem;
+        if (shm) {
+            if (shm_ready(g, Dglobal)) return -1;
+            FS_HIPC(hipStreamSynchronize(st));
+            const int zoff = z_offset(Dglobal);
+            for (int z = 1; z <= g.D; ++z)
+                FS_HIPC(hipMemcpy(shm->gather(zoff + z), s + (size_t)z * plane, plane, hipMemcpyDeviceToHost));
+            if (rank == 0) FS_HIPC(hipMemcpy(shm->gather(0), s, plane, hipMemcpyDeviceToHost));
+            if (rank == nranks - 1)
+                FS_HIPC(hipMemcpy(shm->gather(Dglobal + 1), s + (size_t)(g.D + 1) * plane, plane, hipMemcpyDeviceToHost));
+            shm->barrier();
+            for (int z = 0; z <= Dglobal + 1; ++z)
+                FS_HIPC(hipMemcpy(d + (size_t)z * plane, shm->gather(z), plane, hipMemcpyHostToDevice));
+            shm->barrier();
+            return 0;
+        }
         FS_NCCL(api->AllGather(s + plane, d + plane, plane * (size_t)g.D, ncclInt8, comm, st));
         FS_NCCL(api->Broadcast(s, d, plane, ncclInt8, 0, comm, st));
         FS_NCCL(api->Broadcast(s + (size_t)(g.D + 1) * plane, d + (size_t)(Dglobal + 1) * plane, plane, ncclInt8,
@@ -153,15 +292,49 @@ struct Comm {
         return 0;
     }
 
-    // in-place reductions of {sum, min, max} held in device memory as three doubles
-    int reduce_stats(hipStream_t st, double* d3)
+    // all ranks have finished everything queued before this call
+    int barrier(hipStream_t st, double* d_scratch1)
     {
+        if (!active()) return 0;
+        FS_HIPC(hipStreamSynchronize(st));
+        if (shm) {
+            if (!shm->base) { err = "shared segment not mapped yet"; return -1; }
+            shm->barrier();
+            return 0;
+        }
+        FS_NCCL(api->AllReduce(d_scratch1, d_scratch1, 1, ncclDouble, ncclSum, comm, st));
+        FS_HIPC(hipStreamSynchronize(st));
+        return 0;
+    }
+
+    // in-place reductions of {sum, min, max} held in device memory as three doubles
+    int reduce_stats(hipStream_t st, double* d3, const GridDesc& g, int Dglobal)
+    {
+        if (shm) {
+            if (shm_ready(g, Dglobal)) return -1;
+            double loc[3];
+            FS_HIPC(hipStreamSynchronize(st));
+            FS_HIPC(hipMemcpy(loc, d3, sizeof loc, hipMemcpyDeviceToHost));
+            memcpy(shm->stats(rank), loc, sizeof loc);
+            shm->barrier();
+            double out[3] = { 0.0, 1e300, -1e300 };
+            for (int r = 0; r < nranks; ++r) {
+                const double* q = shm->stats(r);
+                out[0] += q[0];
+                out[1] = q[1] < out[1] ? q[1] : out[1];
+                out[2] = q[2] > out[2] ? q[2] : out[2];
+            }
+            shm->barrier();
+            FS_HIPC(hipMemcpy(d3, out, sizeof out, hipMemcpyHostToDevice));
+            return 0;
+        }
         FS_NCCL(api->AllReduce(d3 + 0, d3 + 0, 1, ncclDouble, ncclSum, comm, st));
         FS_NCCL(api->AllReduce(d3 + 1, d3 + 1, 1, ncclDouble, ncclMin, comm, st));
         FS_NCCL(api->AllReduce(d3 + 2, d3 + 2, 1, ncclDouble, ncclMax, comm, st));
         return 0;
     }
 #undef FS_NCCL
+#undef FS_HIPC
 };
 
 }  // namespace fs

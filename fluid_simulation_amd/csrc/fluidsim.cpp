@@ -251,7 +251,7 @@ struct Engine : EngineBase {
         int rc = unalias(FS_OBS);
         if (rc) return rc;
         if (S->comm.active()) {
-            rc = S->comm.exchange_halo(S->stream, arr[slot[FS_OBS]], g, sizeof(T));
+            rc = S->comm.exchange_halo(S->stream, arr[slot[FS_OBS]], g, sizeof(T), S->D);
             if (rc) return fail(FS_ECOMM, "halo exchange of obs failed: %s", S->comm.last_error());
         }
         ScopedSpan sp(S, FAM_MISC);
@@ -264,7 +264,7 @@ struct Engine : EngineBase {
     {
         if (!S->comm.active()) return FS_OK;
         ScopedSpan sp(S, FAM_COMM);
-        int rc = S->comm.exchange_halo(S->stream, a, g, sizeof(T));
+        int rc = S->comm.exchange_halo(S->stream, a, g, sizeof(T), S->D);
         if (rc) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
         return FS_OK;
     }
@@ -372,8 +372,10 @@ struct Engine : EngineBase {
             fs::launch_divergence<T>(S->stream, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
                                      arr[slot[FS_DIVERGENCE]], arr[slot[FS_PRESSURE]], flags, (T)(-0.5) * h);
         }
-        // divergence of the neighbouring slabs' boundary planes is never read (the solve only
-        // reads rhs at the cell itself) and p is zero everywhere, so no exchange is needed here.
+        // divergence of the neighbouring slabs' boundary planes is never read (the solve only reads
+        // rhs at the cell itself); the pressure halo planes still hold the previous projection and
+        // must become the neighbours' freshly zeroed planes before the first sweep reads them.
+        if ((rc = halo(arr[slot[FS_PRESSURE]]))) return rc;
         int res;
         rc = solve(0, slot[FS_PRESSURE], slot[FS_DIVERGENCE], (T)1, (T)6, S->acc, &res);   // :320
         if (rc) return rc;
@@ -439,7 +441,7 @@ struct Engine : EngineBase {
             if ((rc = unalias(f))) return rc;
         {
             ScopedSpan sp(S, FAM_MISC);
-            fs::launch_inlet_velocity<T>(S->stream, g, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
+            fs::launch_inlet_velocity<T>(S->stream, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
                                          (T)(float)S->speed);   // :103-105
         }
         // :108-110  v_*_prev = v_*  (pre-diffusion snapshot).  Jacobi never writes its input, so
@@ -476,7 +478,7 @@ struct Engine : EngineBase {
         if (rc) return rc;
         {
             ScopedSpan sp(S, FAM_MISC);
-            fs::launch_inlet_density<T>(S->stream, g, arr[slot[FS_DENS]], (T)0.001f);   // :65-67
+            fs::launch_inlet_density<T>(S->stream, g, sc, arr[slot[FS_DENS]], (T)0.001f);   // :65-67
         }
         if (S->solver == FS_SOLVER_GS_LEX || S->acc <= 0 || S->elide_dead) {
             if ((rc = unalias(FS_BUFFER))) return rc;
@@ -553,7 +555,7 @@ struct Engine : EngineBase {
         // the physical ghost planes it holds, and the partial results are all-reduced
         const int zlo = sc.lo_wall ? 0 : 1, zhi = sc.hi_wall ? g.D + 1 : g.D;
         fs::launch_stats<T>(S->stream, g, arr[slot[which]], red + 3 * 1024, red, 3 * 1024, zlo, zhi);
-        if (S->comm.active() && S->comm.reduce_stats(S->stream, red + 3 * 1024))
+        if (S->comm.active() && S->comm.reduce_stats(S->stream, red + 3 * 1024, g, S->D))
             return fail(FS_ECOMM, "stats all-reduce failed: %s", S->comm.last_error());
         HIP_TRY(hipMemcpyAsync(out3, red + 3 * 1024, 3 * sizeof(double), hipMemcpyDeviceToHost, S->stream));
         HIP_TRY(hipStreamSynchronize(S->stream));
@@ -568,13 +570,22 @@ struct Engine : EngineBase {
         const long cells = dense_cells();
         if (!pinned) HIP_TRY(hipHostMalloc(&pinned, cells * sizeof(float), hipHostMallocDefault));
         if (!S->dump_open) {
+            // rank 0 truncates like the reference's ofstream::open (simulation.cpp:56-60); the other
+            // slab ranks open the same files for update once they exist
+            const bool lead = !S->comm.active() || S->comm.rank == 0;
             bool ok = true;
-            for (int k = 0; k < 5; ++k) {
-                std::string path = S->dump_dir + "/" + names[k];
-                // rank 0 truncates like the reference's ofstream::open; other ranks open for update
-                const char* mode = (!S->comm.active() || S->comm.rank == 0) ? "wb" : "r+b";
-                S->dump_fp[k] = fopen(path.c_str(), mode);
-                if (!S->dump_fp[k]) ok = false;
+            for (int pass = 0; pass < 2; ++pass) {
+                if ((pass == 0) == lead) {
+                    for (int k = 0; k < 5; ++k) {
+                        std::string path = S->dump_dir + "/" + names[k];
+                        S->dump_fp[k] = fopen(path.c_str(), lead ? "wb" : "r+b");
+                        if (!S->dump_fp[k]) ok = false;
+                    }
+                }
+                if (pass == 0 && S->comm.active()) {
+                    if (S->comm.shm && S->comm.shm_ready(g, S->D)) return fail(FS_ECOMM, "%s", S->comm.last_error());
+                    if (S->comm.barrier(S->stream, red)) return fail(FS_ECOMM, "dump barrier: %s", S->comm.last_error());
+                }
             }
             if (!ok) {
                 for (int k = 0; k < 5; ++k)

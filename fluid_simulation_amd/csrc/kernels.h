@@ -84,9 +84,9 @@ template <class T>
 void launch_build_flags(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* obs, uint8_t* flags);
 
 template <class T>
-void launch_inlet_velocity(hipStream_t st, const GridDesc& g, T* vx, T* vy, T* vz, T speed);
+void launch_inlet_velocity(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz, T speed);
 template <class T>
-void launch_inlet_density(hipStream_t st, const GridDesc& g, T* dens, T amount);
+void launch_inlet_density(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* dens, T amount);
 
 // dense (reference layout, (W+2)(H+2)(D+2), x fastest) <-> pitched device layout, with
 // element-type conversion.  zlo..zhi (inclusive, local planes) select the planes moved.

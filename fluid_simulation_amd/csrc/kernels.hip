@@ -921,10 +921,10 @@ template void launch_build_flags<double>(hipStream_t, const GridDesc&, const Sla
 // +amount density on the same face (simulation.cpp:65-67).
 // =====================================================================================
 template <class T>
-__global__ void inlet_velocity_kernel(GridDesc g, T* vx, T* vy, T* vz, T speed)
+__global__ void inlet_velocity_kernel(GridDesc g, T* vx, T* vy, T* vz, T speed, int zlo)
 {
     const int y = 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int z = 1 + blockIdx.y;
+    const int z = zlo + blockIdx.y;
     if (y > g.H) return;
     const long c = cell(g, 1, y, z);
     vx[c] = speed;
@@ -932,27 +932,33 @@ __global__ void inlet_velocity_kernel(GridDesc g, T* vx, T* vy, T* vz, T speed)
     vz[c] = (T)0;
 }
 template <class T>
-__global__ void inlet_density_kernel(GridDesc g, T* dens, T amount)
+__global__ void inlet_density_kernel(GridDesc g, T* dens, T amount, int zlo)
 {
     const int y = 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int z = 1 + blockIdx.y;
+    const int z = zlo + blockIdx.y;
     if (y > g.H) return;
     dens[cell(g, 1, y, z)] += amount;
 }
 template <class T>
-void launch_inlet_velocity(hipStream_t st, const GridDesc& g, T* vx, T* vy, T* vz, T speed)
+void launch_inlet_velocity(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz, T speed)
 {
-    hipLaunchKernelGGL((inlet_velocity_kernel<T>), dim3((g.H + 63) / 64, g.D), dim3(64), 0, st, g, vx, vy, vz, speed);
+    // a slab also forces the inlet cells of its halo planes (they are interior planes of the
+    // neighbouring slab), so the halos stay current without an exchange
+    const int zlo = sc.lo_wall ? 1 : 0, zhi = sc.hi_wall ? g.D : g.D + 1;
+    hipLaunchKernelGGL((inlet_velocity_kernel<T>), dim3((g.H + 63) / 64, zhi - zlo + 1), dim3(64), 0, st, g, vx, vy, vz,
+                       speed, zlo);
 }
 template <class T>
-void launch_inlet_density(hipStream_t st, const GridDesc& g, T* dens, T amount)
+void launch_inlet_density(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* dens, T amount)
 {
-    hipLaunchKernelGGL((inlet_density_kernel<T>), dim3((g.H + 63) / 64, g.D), dim3(64), 0, st, g, dens, amount);
+    const int zlo = sc.lo_wall ? 1 : 0, zhi = sc.hi_wall ? g.D : g.D + 1;
+    hipLaunchKernelGGL((inlet_density_kernel<T>), dim3((g.H + 63) / 64, zhi - zlo + 1), dim3(64), 0, st, g, dens, amount,
+                       zlo);
 }
-template void launch_inlet_velocity<float>(hipStream_t, const GridDesc&, float*, float*, float*, float);
-template void launch_inlet_velocity<double>(hipStream_t, const GridDesc&, double*, double*, double*, double);
-template void launch_inlet_density<float>(hipStream_t, const GridDesc&, float*, float);
-template void launch_inlet_density<double>(hipStream_t, const GridDesc&, double*, double);
+template void launch_inlet_velocity<float>(hipStream_t, const GridDesc&, const SlabCtx&, float*, float*, float*, float);
+template void launch_inlet_velocity<double>(hipStream_t, const GridDesc&, const SlabCtx&, double*, double*, double*, double);
+template void launch_inlet_density<float>(hipStream_t, const GridDesc&, const SlabCtx&, float*, float);
+template void launch_inlet_density<double>(hipStream_t, const GridDesc&, const SlabCtx&, double*, double);
 
 // =====================================================================================
 // Layout conversion: pitched device field <-> the reference's dense padded array

@@ -172,7 +172,13 @@ class Simulation:
         check(self._L.fs_comm_init(self._h, rank, nranks, buf))
 
 
-def comm_unique_id():
+def comm_unique_id(transport="rccl"):
+    """128-byte id for fs_comm_init.  "rccl": an ncclUniqueId (RCCL over xGMI, one GPU per rank).
+    "shm": a host-staged development transport through POSIX shared memory, for ranks that
+    are processes on one host and may share a GPU (tests on a 1-GPU box)."""
+    if transport == "shm":
+        name = "FSSHM:/fs_slab_%d_%s" % (os.getpid(), os.urandom(4).hex())
+        return name.encode().ljust(_lib.COMM_ID_BYTES, b"\0")
     buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
     check(_lib.lib().fs_comm_unique_id(buf))
     return buf.raw

@@ -1,0 +1,43 @@
+"""One rank of a z-slab run (spawned by tests/test_gpu_slabs.py).  argv: rank nranks idfile outdir W H D acc steps"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fluid_simulation_amd as F  # noqa: E402
+
+
+def ball(W, H, D, cx, cy, cz, r):
+    z, y, x = np.mgrid[0:D + 2, 0:H + 2, 0:W + 2]
+    m = ((x - cx) ** 2 + (y - cy) ** 2 + (z - cz) ** 2) <= r * r
+    m[0] = m[-1] = False
+    m[:, 0] = m[:, -1] = False
+    m[:, :, 0] = m[:, :, -1] = False
+    return m
+
+
+def main():
+    rank, nranks = int(sys.argv[1]), int(sys.argv[2])
+    idfile, outdir = sys.argv[3], sys.argv[4]
+    W, H, D, acc, steps = (int(v) for v in sys.argv[5:10])
+    stl = sys.argv[10] if len(sys.argv) > 10 else ""
+    sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_dir=os.path.join(outdir, "data"), dump_every=1,
+                       voxel_seed=77)
+    if nranks > 1:
+        sim.comm_init(rank, nranks, open(idfile, "rb").read())
+    Dl, zoff = sim.local_depth, sim.z_offset
+    gmask = ball(W, H, D, W / 3.0, H / 2.0, D / 2.0 + 1.5, min(W, H, D) / 4.0)   # straddles slab boundaries
+    gmask[D // 2, 2, 2] = gmask[D // 2 + 1, 2, 2] = True
+    sim.set_mask(gmask[zoff:zoff + Dl + 2])
+    if stl:
+        F.loadSTLIntoObstacles(stl, sim, 0.5, 0.0, 20.0, 0.0, 3.0, 0.0, 0.0)
+    sim.run()
+    out = {F.FIELD_NAMES[f]: sim.get(f) for f in (F.DENS, F.VX, F.VY, F.VZ, F.OBS, F.PRESSURE)}
+    stats = np.array(sim.stats(F.DENS) + sim.stats(F.VX))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), zoff=zoff, stats=stats, **out)
+    sim.close()
+
+
+if __name__ == "__main__":
+    main()
