@@ -131,9 +131,9 @@ def main():
 
     sim = F.Simulation(W, H, D, args.steps, acc=acc, precision=args.precision, quiet=1, dump_every=0, profile=1)
     if world > 1:
-        ids = [F.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        sim.comm_init(rank, world, ids[0])
+        from fluid_simulation_amd import dist as fsdist
+        uid = fsdist.share_unique_id(dist, F.comm_unique_id, rank, device=torch.device("cuda", local_rank))
+        sim.comm_init(rank, world, uid)
     with tempfile.TemporaryDirectory() as tmp:
         added = add_obstacles(F, sim, cfg, tmp)
 
@@ -149,9 +149,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = fsdist.max_over_ranks(dist, elapsed, device=torch.device("cuda", local_rank))
 
     # dominant kernel: the solver sweep, HIP events on the solver's own stream over the timed
     # region.  Single GPU runs it as jacobi_pair_kernel (two iterations per launch, temporal

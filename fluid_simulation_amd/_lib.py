@@ -58,6 +58,7 @@ _SIGNATURES = {
                                  C.POINTER(C.c_double)]),
     "fs_comm_unique_id": (C.c_int, [C.c_void_p]),
     "fs_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fs_comm_selftest": (C.c_int, []),
     "fs_last_error": (C.c_char_p, []),
     "fs_version": (C.c_char_p, []),
 }

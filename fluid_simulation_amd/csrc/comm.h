@@ -292,6 +292,58 @@ struct Comm {
         return 0;
     }
 
+    // RCCL plumbing check that needs only one GPU: load the library, create a one-rank
+    // communicator and push data through every collective the slab path uses (grouped
+    // send/recv to self, all-gather, broadcast, all-reduce sum/min/max).
+    static int selftest(hipStream_t st, std::string* e)
+    {
+        Comm c;
+        char id[128];
+        if (unique_id(id, e)) return -1;
+        if (c.init(0, 1, id)) { *e = c.err; return -1; }
+        c.nranks = 1;
+        const int n = 4096;
+        double *a = nullptr, *b = nullptr;
+        std::vector<double> h(n), out(n);
+        for (int i = 0; i < n; ++i) h[i] = 0.5 * i - 7.0;
+        int rc = -1;
+        do {
+            if (hipMalloc((void**)&a, n * 8) != hipSuccess || hipMalloc((void**)&b, n * 8) != hipSuccess) { *e = "hipMalloc"; break; }
+            if (hipMemcpy(a, h.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) { *e = "hipMemcpy"; break; }
+            auto same = [&](const char* what) {
+                if (hipStreamSynchronize(st) != hipSuccess) { *e = std::string("sync after ") + what; return false; }
+                if (hipMemcpy(out.data(), b, n * 8, hipMemcpyDeviceToHost) != hipSuccess) { *e = "hipMemcpy back"; return false; }
+                for (int i = 0; i < n; ++i)
+                    if (out[i] != h[i]) { *e = std::string("wrong data after ") + what; return false; }
+                hipMemset(b, 0, n * 8);
+                return true;
+            };
+            ncclResult_t r;
+#define ST(call, what) if ((r = (call)) != ncclSuccess) { *e = std::string(what) + ": " + c.api->GetErrorString(r); break; }
+            ST(c.api->GroupStart(), "GroupStart");
+            ST(c.api->Send(a, n * 8, ncclInt8, 0, c.comm, st), "Send");
+            ST(c.api->Recv(b, n * 8, ncclInt8, 0, c.comm, st), "Recv");
+            ST(c.api->GroupEnd(), "GroupEnd");
+            if (!same("send/recv")) break;
+            ST(c.api->AllGather(a, b, n * 8, ncclInt8, c.comm, st), "AllGather");
+            if (!same("all-gather")) break;
+            ST(c.api->Broadcast(a, b, n * 8, ncclInt8, 0, c.comm, st), "Broadcast");
+            if (!same("broadcast")) break;
+            ST(c.api->AllReduce(a, b, n, ncclDouble, ncclSum, c.comm, st), "AllReduce sum");
+            if (!same("all-reduce sum")) break;
+            ST(c.api->AllReduce(a, b, n, ncclDouble, ncclMin, c.comm, st), "AllReduce min");
+            if (!same("all-reduce min")) break;
+            ST(c.api->AllReduce(a, b, n, ncclDouble, ncclMax, c.comm, st), "AllReduce max");
+            if (!same("all-reduce max")) break;
+#undef ST
+            rc = 0;
+        } while (0);
+        if (a) hipFree(a);
+        if (b) hipFree(b);
+        c.destroy();
+        return rc;
+    }
+
     // all ranks have finished everything queued before this call
     int barrier(hipStream_t st, double* d_scratch1)
     {

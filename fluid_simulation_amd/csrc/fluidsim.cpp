@@ -1017,6 +1017,17 @@ int fs_comm_unique_id(void* id_out)
     return FS_OK;
 }
 
+int fs_comm_selftest(void)
+{
+    std::string err;
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    int rc = fs::Comm::selftest(st, &err);
+    hipStreamDestroy(st);
+    if (rc) return fail(FS_ECOMM, "RCCL self-test: %s", err.c_str());
+    return FS_OK;
+}
+
 int fs_comm_init(fs_sim* s, int rank, int nranks, const void* id)
 {
     if (!s || !id) return fail(FS_EINVAL, "null argument");

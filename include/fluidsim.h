@@ -165,6 +165,11 @@ int fs_comm_unique_id(void* id_out);
  * to fs_create (depth must divide evenly).  Must precede first use. */
 int fs_comm_init(fs_sim* s, int rank, int nranks, const void* id);
 
+/* Loads RCCL, builds a one-rank communicator on the current device and pushes data through
+ * every collective the slab path uses (grouped send/recv, all-gather, broadcast, all-reduce).
+ * A plumbing check for machines with a single GPU. */
+int fs_comm_selftest(void);
+
 const char* fs_last_error(void);
 const char* fs_version(void);
 

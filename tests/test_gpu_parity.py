@@ -339,3 +339,35 @@ def test_one_sweep_at_512_plane_size_matches_oracle(F, oracle_mod):
     sim.linear_solver(2, F.VY, F.VY_PREV, 134.2, 1.0 + 6.0 * 134.2)
     ora.linear_solver(2, O.VY, O.VY0, 134.2, 1.0 + 6.0 * 134.2)
     assert_same(sim.get(F.VY), ora.get(O.VY), "512x512x6 sweep")
+
+
+def test_rccl_plumbing_single_rank(F):
+    """RCCL loads, a one-rank communicator comes up on this GPU, and every collective the slab
+    path uses moves data correctly (the N>1 RCCL path itself needs N GPUs)."""
+    from fluid_simulation_amd import _lib
+    _lib.check(_lib.lib().fs_comm_selftest())
+    uid = F.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+
+
+def test_simulation_out_reference_defaults(tmp_path):
+    """`./simulation.out` with no arguments is the reference's main() (simulation.cpp:429-451):
+    128x64x64, 100 steps, missing STL => empty tunnel; here shortened with --steps, and the
+    dump must have the layout GUI/main_window.py:159-172 expects."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "simulation.out")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ROOT, "simulation.out"])
+    (tmp_path / "data").mkdir()
+    out = subprocess.run([exe, "--steps", "2"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "starting 3-D simulation: 128x64x64  steps = 2" in out.stdout
+    assert "Failed to load STL" in out.stderr                       # object_loader.cpp:283
+    assert "density  min" in out.stdout and "simulation finished" in out.stdout
+    frame = 130 * 66 * 66 * 4
+    for fn in ("data", "obs", "v_x", "v_y", "v_z"):
+        assert os.path.getsize(str(tmp_path / "data" / (fn + ".bin"))) == 2 * frame
+    vx = np.fromfile(str(tmp_path / "data" / "v_x.bin"), dtype=np.float32).reshape(2, 66, 66, 130)
+    assert np.isfinite(vx).all() and vx[-1].max() > 1.0
+    assert not np.fromfile(str(tmp_path / "data" / "obs.bin"), dtype=np.float32).any()
