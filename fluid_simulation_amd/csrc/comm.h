@@ -101,8 +101,8 @@ struct ShmTransport {
 
     static size_t layout(size_t slot, int nranks, int gplanes) { return 4096 + slot * ((size_t)2 * nranks + gplanes) + 4096; }
     char* mailbox(int r, int side) { return base + 4096 + hdr->slot_bytes * ((size_t)2 * r + side); }
-    char* gather(int plane) { return base + 4096 + hdr->slot_bytes * ((size_t)2 * nranks + plane); }
-    double* stats(int r) { return reinterpret_cast<double*>(base + 4096 + hdr->slot_bytes * ((size_t)2 * nranks + hdr->gather_planes)) + 4 * r; }
+    char* gather(int plane) { return base + 4096 + hdr->slot_bytes * ((size_t)2 * nranks) + (hdr->slot_bytes / 2) * (size_t)plane; }
+    double* stats(int r) { return reinterpret_cast<double*>(base + 4096 + hdr->slot_bytes * ((size_t)2 * nranks + hdr->gather_planes)) + 4 * r; }   // gather area over-reserved
 
     // every rank calls this with the same sizes before the first exchange
     int ensure(size_t slot_bytes, int gplanes, std::string* err)
@@ -228,36 +228,44 @@ struct Comm {
     int shm_ready(const GridDesc& g, int Dglobal)
     {
         // slots sized for fp64 planes so that one segment serves every field type
-        return shm->ensure((size_t)g.sz * 8, Dglobal + 2, &err);
+        return shm->ensure((size_t)g.sz * 8 * 2, Dglobal + 2, &err);   // a mailbox slot holds two planes
     }
 
-    // Refresh local planes 0 and D+1 of `a` (LEAD-shifted pointer) from the neighbouring
-    // slabs' planes D and 1.  Physical wall planes (rank 0 low side, last rank high side)
-    // are left alone: the kernels write them.
-    int exchange_halo(hipStream_t st, void* a, const GridDesc& g, size_t elem, int Dglobal = 0)
+    // Refresh the `depth` halo planes on each slab side of `a` (shifted pointer: plane z starts at
+    // a + z*sz) from the neighbouring slabs' outermost `depth` interior planes.  Physical wall
+    // planes (rank 0 low side, last rank high side) are left alone: the kernels write them.
+    int exchange_halo(hipStream_t st, void* a, const GridDesc& g, size_t elem, int Dglobal, int depth)
     {
         if (!active()) return 0;
         char* base = static_cast<char*>(a);
         const size_t plane = (size_t)g.sz * elem;
+        const size_t bytes = plane * (size_t)depth;
+        char* send_lo = base + plane;                                   // planes 1 .. depth
+        char* recv_lo = base - (ptrdiff_t)(plane * (size_t)(depth - 1));   // planes 1-depth .. 0
+        char* send_hi = base + plane * (size_t)(g.D - depth + 1);       // planes D-depth+1 .. D
+        char* recv_hi = base + plane * (size_t)(g.D + 1);               // planes D+1 .. D+depth
         if (shm) {
-            if (shm_ready(g, Dglobal ? Dglobal : g.D * nranks)) return -1;
+            if (depth > 2) { err = "shm transport carries at most two planes"; return -1; }
+            if (shm_ready(g, Dglobal)) return -1;
             FS_HIPC(hipStreamSynchronize(st));
-            if (rank > 0) FS_HIPC(hipMemcpy(shm->mailbox(rank - 1, 1), base + plane, plane, hipMemcpyDeviceToHost));
-            if (rank < nranks - 1) FS_HIPC(hipMemcpy(shm->mailbox(rank + 1, 0), base + (size_t)g.D * plane, plane, hipMemcpyDeviceToHost));
+            if (rank > 0) FS_HIPC(hipMemcpyAsync(shm->mailbox(rank - 1, 1), send_lo, bytes, hipMemcpyDeviceToHost, st));
+            if (rank < nranks - 1) FS_HIPC(hipMemcpyAsync(shm->mailbox(rank + 1, 0), send_hi, bytes, hipMemcpyDeviceToHost, st));
+            FS_HIPC(hipStreamSynchronize(st));
             shm->barrier();
-            if (rank > 0) FS_HIPC(hipMemcpy(base, shm->mailbox(rank, 0), plane, hipMemcpyHostToDevice));
-            if (rank < nranks - 1) FS_HIPC(hipMemcpy(base + (size_t)(g.D + 1) * plane, shm->mailbox(rank, 1), plane, hipMemcpyHostToDevice));
+            if (rank > 0) FS_HIPC(hipMemcpyAsync(recv_lo, shm->mailbox(rank, 0), bytes, hipMemcpyHostToDevice, st));
+            if (rank < nranks - 1) FS_HIPC(hipMemcpyAsync(recv_hi, shm->mailbox(rank, 1), bytes, hipMemcpyHostToDevice, st));
+            FS_HIPC(hipStreamSynchronize(st));
             shm->barrier();
             return 0;
         }
         FS_NCCL(api->GroupStart());
         if (rank > 0) {
-            FS_NCCL(api->Send(base + 1 * plane, plane, ncclInt8, rank - 1, comm, st));
-            FS_NCCL(api->Recv(base + 0 * plane, plane, ncclInt8, rank - 1, comm, st));
+            FS_NCCL(api->Send(send_lo, bytes, ncclInt8, rank - 1, comm, st));
+            FS_NCCL(api->Recv(recv_lo, bytes, ncclInt8, rank - 1, comm, st));
         }
         if (rank < nranks - 1) {
-            FS_NCCL(api->Send(base + (size_t)g.D * plane, plane, ncclInt8, rank + 1, comm, st));
-            FS_NCCL(api->Recv(base + (size_t)(g.D + 1) * plane, plane, ncclInt8, rank + 1, comm, st));
+            FS_NCCL(api->Send(send_hi, bytes, ncclInt8, rank + 1, comm, st));
+            FS_NCCL(api->Recv(recv_hi, bytes, ncclInt8, rank + 1, comm, st));
         }
         FS_NCCL(api->GroupEnd());
         return 0;
@@ -275,13 +283,15 @@ struct Comm {
             FS_HIPC(hipStreamSynchronize(st));
             const int zoff = z_offset(Dglobal);
             for (int z = 1; z <= g.D; ++z)
-                FS_HIPC(hipMemcpy(shm->gather(zoff + z), s + (size_t)z * plane, plane, hipMemcpyDeviceToHost));
-            if (rank == 0) FS_HIPC(hipMemcpy(shm->gather(0), s, plane, hipMemcpyDeviceToHost));
+                FS_HIPC(hipMemcpyAsync(shm->gather(zoff + z), s + (size_t)z * plane, plane, hipMemcpyDeviceToHost, st));
+            if (rank == 0) FS_HIPC(hipMemcpyAsync(shm->gather(0), s, plane, hipMemcpyDeviceToHost, st));
             if (rank == nranks - 1)
-                FS_HIPC(hipMemcpy(shm->gather(Dglobal + 1), s + (size_t)(g.D + 1) * plane, plane, hipMemcpyDeviceToHost));
+                FS_HIPC(hipMemcpyAsync(shm->gather(Dglobal + 1), s + (size_t)(g.D + 1) * plane, plane, hipMemcpyDeviceToHost, st));
+            FS_HIPC(hipStreamSynchronize(st));
             shm->barrier();
             for (int z = 0; z <= Dglobal + 1; ++z)
-                FS_HIPC(hipMemcpy(d + (size_t)z * plane, shm->gather(z), plane, hipMemcpyHostToDevice));
+                FS_HIPC(hipMemcpyAsync(d + (size_t)z * plane, shm->gather(z), plane, hipMemcpyHostToDevice, st));
+            FS_HIPC(hipStreamSynchronize(st));
             shm->barrier();
             return 0;
         }
@@ -309,13 +319,15 @@ struct Comm {
         int rc = -1;
         do {
             if (hipMalloc((void**)&a, n * 8) != hipSuccess || hipMalloc((void**)&b, n * 8) != hipSuccess) { *e = "hipMalloc"; break; }
-            if (hipMemcpy(a, h.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) { *e = "hipMemcpy"; break; }
+            if (hipMemcpyAsync(a, h.data(), n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemsetAsync(b, 0, n * 8, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { *e = "hipMemcpyAsync"; break; }
             auto same = [&](const char* what) {
                 if (hipStreamSynchronize(st) != hipSuccess) { *e = std::string("sync after ") + what; return false; }
-                if (hipMemcpy(out.data(), b, n * 8, hipMemcpyDeviceToHost) != hipSuccess) { *e = "hipMemcpy back"; return false; }
+                if (hipMemcpyAsync(out.data(), b, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) { *e = "hipMemcpy back"; return false; }
                 for (int i = 0; i < n; ++i)
                     if (out[i] != h[i]) { *e = std::string("wrong data after ") + what; return false; }
-                hipMemset(b, 0, n * 8);
+                if (hipMemsetAsync(b, 0, n * 8, st) != hipSuccess) { *e = "hipMemsetAsync"; return false; }
                 return true;
             };
             ncclResult_t r;
@@ -366,7 +378,8 @@ struct Comm {
             if (shm_ready(g, Dglobal)) return -1;
             double loc[3];
             FS_HIPC(hipStreamSynchronize(st));
-            FS_HIPC(hipMemcpy(loc, d3, sizeof loc, hipMemcpyDeviceToHost));
+            FS_HIPC(hipMemcpyAsync(loc, d3, sizeof loc, hipMemcpyDeviceToHost, st));
+            FS_HIPC(hipStreamSynchronize(st));
             memcpy(shm->stats(rank), loc, sizeof loc);
             shm->barrier();
             double out[3] = { 0.0, 1e300, -1e300 };
@@ -377,7 +390,8 @@ struct Comm {
                 out[2] = q[2] > out[2] ? q[2] : out[2];
             }
             shm->barrier();
-            FS_HIPC(hipMemcpy(d3, out, sizeof out, hipMemcpyHostToDevice));
+            FS_HIPC(hipMemcpyAsync(d3, out, sizeof out, hipMemcpyHostToDevice, st));
+            FS_HIPC(hipStreamSynchronize(st));
             return 0;
         }
         FS_NCCL(api->AllReduce(d3 + 0, d3 + 0, 1, ncclDouble, ncclSum, comm, st));

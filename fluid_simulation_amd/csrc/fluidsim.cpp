@@ -162,8 +162,9 @@ struct Engine : EngineBase {
     T* arr[NPOOL] = {nullptr};          // LEAD-shifted pointers
     int slot[FS_NFIELDS];               // field -> array id (aliases allowed inside a step)
     bool held[NPOOL] = {false};         // temporaries owned by a running solve
-    uint8_t* flags = nullptr;           // LEAD-shifted
+    uint8_t* flags = nullptr;           // shifted like the fields
     bool flags_dirty = true;
+    bool halos_dirty = false;           // a host-side mutation may have changed a slab boundary plane
     void* dense = nullptr;              // device staging for pack/unpack: dense local slab, sizeof(double) per cell
     void* pinned = nullptr;             // host staging for dumps
     T* gathered = nullptr;              // all-gathered advection source (z-slabs only), LEAD-shifted
@@ -181,7 +182,9 @@ struct Engine : EngineBase {
         g.D = cm.active() ? cm.local_depth(S->D) : S->D;
         g.sy = ((long)(g.W + 5) + 3) / 4 * 4;
         g.sz = g.sy * (g.H + 2);
-        g.n = g.sz * (g.D + 2) + 8;    // LEAD + tail so that a dwordx4 at the last ghost stays in bounds
+        g.zh = cm.active() ? 2 : 1;    // z-slabs keep two halo planes per side (pair kernel across slab boundaries)
+        g.lead = fs::LEAD + (long)(g.zh - 1) * g.sz;
+        g.n = g.sz * (g.D + 2 * g.zh) + 8;   // lead + tail so that a dwordx4 at the last ghost stays in bounds
         g.n = (g.n + 3) / 4 * 4;
         sc.zoff = cm.active() ? cm.z_offset(S->D) : 0;
         sc.Dglobal = S->D;
@@ -191,13 +194,13 @@ struct Engine : EngineBase {
             T* base = nullptr;
             HIP_TRY(hipMalloc((void**)&base, g.n * sizeof(T)));
             HIP_TRY(hipMemsetAsync(base, 0, g.n * sizeof(T), S->stream));   // simulation.cpp:38-43
-            arr[i] = base + fs::LEAD;
+            arr[i] = base + g.lead;
         }
         for (int f = 0; f < FS_NFIELDS; ++f) slot[f] = f;
         uint8_t* fb = nullptr;
         HIP_TRY(hipMalloc((void**)&fb, g.n));
         HIP_TRY(hipMemsetAsync(fb, 0, g.n, S->stream));
-        flags = fb + fs::LEAD;
+        flags = fb + g.lead;
         HIP_TRY(hipMalloc(&dense, dense_cells() * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&red, NRED * sizeof(double)));
         return FS_OK;
@@ -206,9 +209,9 @@ struct Engine : EngineBase {
     ~Engine() override
     {
         for (int i = 0; i < NPOOL; ++i)
-            if (arr[i]) hipFree(arr[i] - fs::LEAD);
-        if (flags) hipFree(flags - fs::LEAD);
-        if (gathered) hipFree(gathered - fs::LEAD);
+            if (arr[i]) hipFree(arr[i] - g.lead);
+        if (flags) hipFree(flags - g.lead);
+        if (gathered) hipFree(gathered - fs::LEAD);   // global array with one ghost plane per side
         if (dense) hipFree(dense);
         if (pinned) hipHostFree(pinned);
         if (red) hipFree(red);
@@ -245,13 +248,33 @@ struct Engine : EngineBase {
         return FS_OK;
     }
 
+    // Host-side writes (fs_set_field, fs_add_density, ...) reach only this rank's planes; before
+    // the next kernel every rank refreshes the halo copies of all fields (collective).
+    int ensure_halos()
+    {
+        if (!halos_dirty || !S->comm.active()) { halos_dirty = false; return FS_OK; }
+        halos_dirty = false;
+        bool done[NPOOL] = {false};
+        for (int f = 0; f < FS_NFIELDS; ++f) {
+            if (f == FS_OBS || done[slot[f]]) continue;
+            done[slot[f]] = true;
+            int rc = halo(arr[slot[f]]);
+            if (rc) return rc;
+        }
+        return FS_OK;
+    }
+
     int ensure_flags()
     {
+        {
+            int rc = ensure_halos();
+            if (rc) return rc;
+        }
         if (!flags_dirty) return FS_OK;
         int rc = unalias(FS_OBS);
         if (rc) return rc;
         if (S->comm.active()) {
-            rc = S->comm.exchange_halo(S->stream, arr[slot[FS_OBS]], g, sizeof(T), S->D);
+            rc = S->comm.exchange_halo(S->stream, arr[slot[FS_OBS]], g, sizeof(T), S->D, g.zh);
             if (rc) return fail(FS_ECOMM, "halo exchange of obs failed: %s", S->comm.last_error());
         }
         ScopedSpan sp(S, FAM_MISC);
@@ -264,7 +287,7 @@ struct Engine : EngineBase {
     {
         if (!S->comm.active()) return FS_OK;
         ScopedSpan sp(S, FAM_COMM);
-        int rc = S->comm.exchange_halo(S->stream, a, g, sizeof(T), S->D);
+        int rc = S->comm.exchange_halo(S->stream, a, g, sizeof(T), S->D, g.zh);
         if (rc) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
         return FS_OK;
     }
@@ -287,13 +310,19 @@ struct Engine : EngineBase {
         int src = cur;
         bool src_temp = false;
         const bool pairs = fs::pair_supported<T>(g, sc);
+        if (pairs && S->comm.active()) {
+            // the pair kernel recomputes level 1 of the neighbours' boundary planes: it reads the
+            // right-hand side there, so its first halo plane must be current
+            int rc = halo(arr[rhs]);
+            if (rc) return rc;
+        }
         for (int it = 0; it < sweeps; ++it) {
             int dst = acquire(src, rhs);
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
             if (pairs && it + 1 < sweeps) {
                 // two sweeps per pass over memory; timed as its own family, one launch each
                 ScopedSpan sp(S, FAM_PAIR);
-                fs::launch_jacobi_pair<T>(S->stream, g, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c);
+                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c);
                 ++it;
             } else {
                 ScopedSpan sp(S, FAM_SWEEP);
@@ -474,8 +503,9 @@ struct Engine : EngineBase {
     // one iteration of Simulation::run()'s loop (simulation.cpp:63-71)
     int run_one() override
     {
-        int rc = unalias(FS_DENS);
+        int rc = ensure_halos();
         if (rc) return rc;
+        if ((rc = unalias(FS_DENS))) return rc;
         {
             ScopedSpan sp(S, FAM_MISC);
             fs::launch_inlet_density<T>(S->stream, g, sc, arr[slot[FS_DENS]], (T)0.001f);   // :65-67
@@ -521,6 +551,7 @@ struct Engine : EngineBase {
         else fs::launch_unpack<T, uint8_t>(S->stream, g, (const uint8_t*)dense, f, 0, g.D + 1);
         HIP_TRY(hipStreamSynchronize(S->stream));       // `src` may be freed by the caller
         if (which == FS_OBS) flags_dirty = true;
+        else halos_dirty = true;
         return FS_OK;
     }
 
@@ -536,6 +567,7 @@ struct Engine : EngineBase {
         long idx = (long)x + (long)y * g.sy + (long)zl * g.sz;
         fs::launch_point_add<T>(S->stream, arr[slot[which]], idx, (T)v, set_instead);
         if (which == FS_OBS) flags_dirty = true;
+        else halos_dirty = true;
         return FS_OK;
     }
 
@@ -641,7 +673,7 @@ struct Engine : EngineBase {
         const bool pairs = fs::pair_supported<T>(g, sc);
         for (int r = 0; r < reps; ++r) {
             if (pairs && r + 1 < reps) {
-                fs::launch_jacobi_pair<T>(S->stream, g, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c);
+                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c);
                 ++r;
             } else {
                 fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c, 1, g.D);

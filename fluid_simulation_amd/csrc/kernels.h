@@ -14,7 +14,10 @@ namespace fs {
 struct GridDesc {
     int W, H, D;   // interior extents of THIS slab (D = local planes under z-slab partitioning)
     long sy, sz;   // row and plane pitch in elements
-    long n;        // elements per allocation (including LEAD and the tail pad)
+    long n;        // elements per allocation (including `lead` and the tail pad)
+    long lead;     // elements between the allocation base and p: LEAD + (zh-1) planes
+    int zh;        // halo planes kept on each z side: 1 (single GPU) or 2 (z-slabs: planes -1..D+2
+                   // exist so that two fused sweeps can cross a slab boundary)
 };
 constexpr int LEAD = 3;
 
@@ -52,12 +55,13 @@ void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T
                    const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last);
 
 // Two sweeps in one pass (temporal blocking); same result as two launch_jacobi calls.
-// Only for a slab that holds both physical z walls (single GPU) and W <= 1024.
+// Needs W <= 1024; on a z-slab additionally two halo planes per side (g.zh == 2), current in
+// `src`, and one current halo plane of `rhs` and `flags`.
 template <class T>
 bool pair_supported(const GridDesc& g, const SlabCtx& sc);
 template <class T>
-void launch_jacobi_pair(hipStream_t st, const GridDesc& g, const T* src, const T* rhs, T* dst, const uint8_t* flags,
-                        int b, T a, T inv_c);
+void launch_jacobi_pair(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
+                        const uint8_t* flags, int b, T a, T inv_c);
 
 template <class T>
 void launch_gs_lex(hipStream_t st, const GridDesc& g, T* q, const T* rhs, const uint8_t* flags, int b, T a, T inv_c,

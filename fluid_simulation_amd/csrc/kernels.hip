@@ -281,7 +281,7 @@ template void launch_jacobi<double>(hipStream_t, const GridDesc&, const SlabCtx&
 // neighbour row belongs to the next band); rows next to the walls use the ghost rows.
 // =====================================================================================
 template <class T, int NXW, int NYW>
-__global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, const T* __restrict__ src,
+__global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                                      const T* __restrict__ rhs, T* __restrict__ dst,
                                                                      const uint8_t* __restrict__ flags, int b, T a,
                                                                      T inv_c, int zc_len, int nbands, int nblk)
@@ -301,7 +301,10 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
     const bool lane_on = x0 <= W;
     const int zbeg = 1 + zc * zc_len, zend = min(D, zbeg + zc_len - 1);   // level-2 output planes
     if (zbeg > zend) return;                             // block-uniform
-    const int zl_first = max(1, zbeg - 1), zl_last = min(D, zend + 1);    // level-1 planes
+    // level-1 planes: one beyond the output chunk on each side; beyond a physical wall there is
+    // no such plane (its level-1 ghost is derived below), beyond a slab boundary it is the
+    // neighbour's plane, recomputed here from the two-deep halo
+    const int zl_first = max(sc.lo_wall ? 1 : 0, zbeg - 1), zl_last = min(sc.hi_wall ? D : D + 1, zend + 1);
     const int out_lo = max(1, s + 1), out_hi = min(H, s + BY - 2);        // level-2 output rows
 
     const bool full_group = (x0 + 3 <= W);
@@ -411,7 +414,8 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
             *reinterpret_cast<V4<T>*>(dst + base) = q;
             if (x0 == 1) dst[base - 1] = (b == 1) ? -u[0] : u[0];                               // :189-190
             if (full_group && x0 + 3 == W) dst[base + 4] = u[3];                               // :191
-            if (y == 1 || y == H || zo == 1 || zo == D) {
+            const bool zlo_face = (zo == 1) && sc.lo_wall, zhi_face = (zo == D) && sc.hi_wall;
+            if (y == 1 || y == H || zlo_face || zhi_face) {
                 T f[4];
                 V4<T> qq;
                 face4(u, b == 2, f);
@@ -422,8 +426,8 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
                 face4(u, b == 3, f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qq.e[e] = f[e];
-                if (zo == 1) *reinterpret_cast<V4<T>*>(dst + base - g.sz) = qq;                 // :208-214
-                if (zo == D) *reinterpret_cast<V4<T>*>(dst + base + g.sz) = qq;
+                if (zlo_face) *reinterpret_cast<V4<T>*>(dst + base - g.sz) = qq;                // :208-214
+                if (zhi_face) *reinterpret_cast<V4<T>*>(dst + base + g.sz) = qq;
             }
         }
     };
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
             }
             face4(u, b == 3, gz[r]);
         }
-        if (zl == 1) {                                   // level-1 ghost plane z = 0 (:208-210)
+        if (zl == 1 && sc.lo_wall) {                     // level-1 ghost plane z = 0 (:208-210)
 #pragma unroll
             for (int r = 0; r < RY; ++r)
                 if (lane_on && y0 + r >= 1 && y0 + r <= H) lds_put(0, ty0 + r, gz[r]);
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 
         // ---- level 2 of plane zl-1
         if (zl - 1 >= zbeg) level2(zl - 1, xm);
-        if (zl == D && zend == D) {
+        if (zl == D && zend == D && sc.hi_wall) {
             // top wall: level-1 ghost plane z = D+1 is +-u1(D) (:212-214).  Its ring slot still
             // holds plane D-3, which slower waves may be reading: fence both sides.
             __syncthreads();
@@ -505,8 +509,8 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 }
 
 template <class T, int NXW, int NYW>
-static void launch_pair_v(hipStream_t st, const GridDesc& g, const T* src, const T* rhs, T* dst, const uint8_t* flags,
-                          int b, T a, T inv_c)
+static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
+                          const uint8_t* flags, int b, T a, T inv_c)
 {
     constexpr int BY = NYW * 2;
     const SweepTune& tune = sweep_tune();
@@ -527,25 +531,26 @@ static void launch_pair_v(hipStream_t st, const GridDesc& g, const T* src, const
     if (tune.pair_zc > 0) zc_len = tune.pair_zc < g.D ? tune.pair_zc : g.D;
     const int nzc = (g.D + zc_len - 1) / zc_len;
     const int nblk = nbands * nzc;
-    hipLaunchKernelGGL((jacobi_pair_kernel<T, NXW, NYW>), dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, src, rhs, dst,
-                       flags, b, a, inv_c, zc_len, nbands, nblk);
+    hipLaunchKernelGGL((jacobi_pair_kernel<T, NXW, NYW>), dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, sc, src, rhs,
+                       dst, flags, b, a, inv_c, zc_len, nbands, nblk);
 }
 
 template <class T>
 bool pair_supported(const GridDesc& g, const SlabCtx& sc)
 {
-    return sc.lo_wall && sc.hi_wall && g.W <= 1024 && sweep_tune().fuse >= 2;
+    const bool whole = sc.lo_wall && sc.hi_wall;
+    return (whole || g.zh >= 2) && g.W <= 1024 && sweep_tune().fuse >= 2;
 }
 template bool pair_supported<float>(const GridDesc&, const SlabCtx&);
 template bool pair_supported<double>(const GridDesc&, const SlabCtx&);
 
 template <>
-void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const float* src, const float* rhs, float* dst,
-                               const uint8_t* flags, int b, float a, float inv_c)
+void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const float* src, const float* rhs,
+                               float* dst, const uint8_t* flags, int b, float a, float inv_c)
 {
     const int nxw = (g.W + 255) / 256;
     const int shape = sweep_tune().pair_small;   // 0 = default (768 threads: 12 waves at <=168 VGPRs, one block per CU)
-#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, src, rhs, dst, flags, b, a, inv_c)
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
@@ -553,14 +558,14 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const float* s
 #undef FS_PAIR
 }
 template <>
-void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const double* src, const double* rhs, double* dst,
-                                const uint8_t* flags, int b, double a, double inv_c)
+void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const double* src,
+                                const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c)
 {
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
-    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, src, rhs, dst, flags, b, a, inv_c);
-    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, src, rhs, dst, flags, b, a, inv_c);
-    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, src, rhs, dst, flags, b, a, inv_c);
-    else launch_pair_v<double, 4, 2>(st, g, src, rhs, dst, flags, b, a, inv_c);
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c);
+    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c);
 }
 
 // =====================================================================================
@@ -880,11 +885,12 @@ template void launch_advect<double>(hipStream_t, const GridDesc&, const SlabCtx&
 // neighbouring slabs' cells.
 // =====================================================================================
 template <class T>
-__global__ void build_flags_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ obs, uint8_t* __restrict__ flags)
+__global__ void build_flags_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ obs, uint8_t* __restrict__ flags,
+                                   int zlo)
 {
     const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int z = 1 + blockIdx.z;
+    const int z = zlo + blockIdx.z;
     if (x > g.W || y > g.H) return;
     const long c = cell(g, x, y, z);
     const int zg = z + sc.zoff;
@@ -911,7 +917,12 @@ __global__ void build_flags_kernel(GridDesc g, SlabCtx sc, const T* __restrict__
 template <class T>
 void launch_build_flags(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* obs, uint8_t* flags)
 {
-    hipLaunchKernelGGL((build_flags_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, obs, flags);
+    // with two-deep halos the flags of the first halo plane on a slab side are needed too (the
+    // pair kernel recomputes level 1 of that plane); their z neighbours are the second halo plane
+    const int zlo = (g.zh >= 2 && !sc.lo_wall) ? 0 : 1, zhi = (g.zh >= 2 && !sc.hi_wall) ? g.D + 1 : g.D;
+    dim3 grid = cell_grid(g);
+    grid.z = zhi - zlo + 1;
+    hipLaunchKernelGGL((build_flags_kernel<T>), grid, cell_block(), 0, st, g, sc, obs, flags, zlo);
 }
 template void launch_build_flags<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, uint8_t*);
 template void launch_build_flags<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, uint8_t*);
@@ -944,14 +955,14 @@ void launch_inlet_velocity(hipStream_t st, const GridDesc& g, const SlabCtx& sc,
 {
     // a slab also forces the inlet cells of its halo planes (they are interior planes of the
     // neighbouring slab), so the halos stay current without an exchange
-    const int zlo = sc.lo_wall ? 1 : 0, zhi = sc.hi_wall ? g.D : g.D + 1;
+    const int zlo = sc.lo_wall ? 1 : 1 - g.zh, zhi = sc.hi_wall ? g.D : g.D + g.zh;
     hipLaunchKernelGGL((inlet_velocity_kernel<T>), dim3((g.H + 63) / 64, zhi - zlo + 1), dim3(64), 0, st, g, vx, vy, vz,
                        speed, zlo);
 }
 template <class T>
 void launch_inlet_density(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* dens, T amount)
 {
-    const int zlo = sc.lo_wall ? 1 : 0, zhi = sc.hi_wall ? g.D : g.D + 1;
+    const int zlo = sc.lo_wall ? 1 : 1 - g.zh, zhi = sc.hi_wall ? g.D : g.D + g.zh;
     hipLaunchKernelGGL((inlet_density_kernel<T>), dim3((g.H + 63) / 64, zhi - zlo + 1), dim3(64), 0, st, g, dens, amount,
                        zlo);
 }
@@ -1016,9 +1027,9 @@ __global__ void copy_kernel(const T* __restrict__ src, T* __restrict__ dst, long
 template <class T>
 void launch_copy(hipStream_t st, const GridDesc& g, const T* src, T* dst)
 {
-    // src/dst are the LEAD-shifted pointers; copy the underlying allocations
+    // src/dst are the shifted pointers; copy the underlying allocations
     long n4 = g.n / 4;
-    hipLaunchKernelGGL((copy_kernel<T>), dim3(2048), dim3(256), 0, st, src - LEAD, dst - LEAD, n4);
+    hipLaunchKernelGGL((copy_kernel<T>), dim3(2048), dim3(256), 0, st, src - g.lead, dst - g.lead, n4);
 }
 template void launch_copy<float>(hipStream_t, const GridDesc&, const float*, float*);
 template void launch_copy<double>(hipStream_t, const GridDesc&, const double*, double*);

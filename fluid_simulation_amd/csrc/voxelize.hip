@@ -256,8 +256,8 @@ __global__ void mark_cells_kernel(GridDesc g, SlabCtx sc, T* obs, const int* __r
     const int id = cells[i];
     const int x = id % (g.W + 2), y = (id / (g.W + 2)) % (g.H + 2), z = id / ((g.W + 2) * (g.H + 2));
     const int zl = z - sc.zoff;
-    // a slab also records the solids of its two halo planes (the flag build reads them)
-    if (zl < 0 || zl > g.D + 1) return;
+    // a slab also records the solids of its halo planes (the flag build reads them)
+    if (zl < 1 - g.zh || zl > g.D + g.zh) return;
     obs[(long)x + (long)y * g.sy + (long)zl * g.sz] = (T)1;     // Simulation::addObstacle, simulation.cpp:157
 }
 
