@@ -302,6 +302,83 @@ struct Comm {
         return 0;
     }
 
+    // Planes of the global array that rank `i` reads when every back-trace stays within `reach`
+    // planes of its own slab, as an inclusive global range.
+    void window(int i, int Dglobal, int reach, int& lo, int& hi) const
+    {
+        const int dl = Dglobal / nranks;
+        lo = i * dl + 1 - reach;
+        hi = i * dl + dl + reach;
+        if (lo < 0) lo = 0;
+        if (hi > Dglobal + 1) hi = Dglobal + 1;
+    }
+    // Global planes rank `j` can provide: its interior planes plus the physical ghost plane it holds.
+    void owned(int j, int Dglobal, int& lo, int& hi) const
+    {
+        const int dl = Dglobal / nranks;
+        lo = (j == 0) ? 0 : j * dl + 1;
+        hi = (j == nranks - 1) ? Dglobal + 1 : j * dl + dl;
+    }
+
+    // Windowed gather of the advection source: `dst` is the global array (planes 0..Dglobal+1);
+    // on return it holds, for this rank, every plane within `reach` of its slab.  Each pair of
+    // ranks whose window/ownership ranges intersect exchanges exactly that intersection
+    // (grouped ncclSend/ncclRecv); the own planes are a device-to-device copy.
+    int gather_window(hipStream_t st, const void* src, void* dst, const GridDesc& g, int Dglobal, size_t elem, int reach)
+    {
+        const char* s = static_cast<const char*>(src);
+        char* d = static_cast<char*>(dst);
+        const size_t plane = (size_t)g.sz * elem;
+        const int zoff = z_offset(Dglobal);
+        int mylo, myhi, ownlo, ownhi;
+        window(rank, Dglobal, reach, mylo, myhi);
+        owned(rank, Dglobal, ownlo, ownhi);
+        FS_HIPC(hipMemcpyAsync(d + (size_t)ownlo * plane, s + (ptrdiff_t)(ownlo - zoff) * (ptrdiff_t)plane,
+                               plane * (size_t)(ownhi - ownlo + 1), hipMemcpyDeviceToDevice, st));
+        if (shm) {
+            if (shm_ready(g, Dglobal)) return -1;
+            // stage what others need of mine, then pick up what I need of theirs
+            for (int j = 0; j < nranks; ++j) {
+                if (j == rank) continue;
+                int wlo, whi;
+                window(j, Dglobal, reach, wlo, whi);
+                const int lo = wlo > ownlo ? wlo : ownlo, hi = whi < ownhi ? whi : ownhi;
+                for (int z = lo; z <= hi; ++z)
+                    FS_HIPC(hipMemcpyAsync(shm->gather(z), s + (ptrdiff_t)(z - zoff) * (ptrdiff_t)plane, plane,
+                                           hipMemcpyDeviceToHost, st));
+            }
+            FS_HIPC(hipStreamSynchronize(st));
+            shm->barrier();
+            for (int j = 0; j < nranks; ++j) {
+                if (j == rank) continue;
+                int olo, ohi;
+                owned(j, Dglobal, olo, ohi);
+                const int lo = mylo > olo ? mylo : olo, hi = myhi < ohi ? myhi : ohi;
+                for (int z = lo; z <= hi; ++z)
+                    FS_HIPC(hipMemcpyAsync(d + (size_t)z * plane, shm->gather(z), plane, hipMemcpyHostToDevice, st));
+            }
+            FS_HIPC(hipStreamSynchronize(st));
+            shm->barrier();
+            return 0;
+        }
+        FS_NCCL(api->GroupStart());
+        for (int j = 0; j < nranks; ++j) {
+            if (j == rank) continue;
+            int wlo, whi, olo, ohi;
+            window(j, Dglobal, reach, wlo, whi);
+            int lo = wlo > ownlo ? wlo : ownlo, hi = whi < ownhi ? whi : ownhi;
+            if (lo <= hi)
+                FS_NCCL(api->Send(s + (ptrdiff_t)(lo - zoff) * (ptrdiff_t)plane, plane * (size_t)(hi - lo + 1), ncclInt8, j,
+                                  comm, st));
+            owned(j, Dglobal, olo, ohi);
+            lo = mylo > olo ? mylo : olo;
+            hi = myhi < ohi ? myhi : ohi;
+            if (lo <= hi) FS_NCCL(api->Recv(d + (size_t)lo * plane, plane * (size_t)(hi - lo + 1), ncclInt8, j, comm, st));
+        }
+        FS_NCCL(api->GroupEnd());
+        return 0;
+    }
+
     // RCCL plumbing check that needs only one GPU: load the library, create a one-rank
     // communicator and push data through every collective the slab path uses (grouped
     // send/recv to self, all-gather, broadcast, all-reduce sum/min/max).

@@ -87,6 +87,8 @@ struct fs_sim {
     int dump_every = 1;
     unsigned voxel_seed = 1;
     bool quiet = false, profile = false, elide_dead = false;
+    bool debug_poison = false;   // fill the gathered advection source with NaN bit patterns before each gather
+    int last_reach = 0;          // planes of reach used by the most recent slab advection
     // device
     int device = 0;
     hipStream_t stream = nullptr;
@@ -438,7 +440,10 @@ struct Engine : EngineBase {
         const T* src = arr[slot[prev]];
         long zshift = 0;
         if (S->comm.active()) {
-            // the back-trace may leave the slab (dt*D*|v_z| planes): gather the whole source
+            // The back-trace may leave the slab by dt*D*|u_z| planes.  Bound it: the
+            // carrying z velocity is `prev` for b == 3 and the current v_z otherwise
+            // (simulation.cpp:382); its global max |.| gives the reach in planes, and only planes
+            // within that reach of the slab are fetched from their owners.
             if (!gathered) {
                 T* base = nullptr;
                 long n = g.sz * ((long)S->D + 2) + 8;
@@ -447,8 +452,18 @@ struct Engine : EngineBase {
                 gathered = base + fs::LEAD;
             }
             ScopedSpan sp(S, FAM_COMM);
-            rc = S->comm.all_gather_planes(S->stream, src, gathered, g, S->D, sizeof(T));
-            if (rc) return fail(FS_ECOMM, "all-gather of the advection source failed: %s", S->comm.last_error());
+            double st3[3];
+            if ((rc = stats_of(arr[slot[b == 3 ? prev : FS_VZ]], st3))) return rc;
+            const double umax = std::fmax(std::fabs(st3[1]), std::fabs(st3[2]));
+            const double planes = std::ceil(std::fabs((double)kz) * umax) + 2.0;   // floor() and the +1 corner
+            const int reach = planes >= (double)S->D ? S->D : (int)planes;
+            S->last_reach = reach;
+            if (S->debug_poison) HIP_TRY(hipMemsetAsync(gathered - fs::LEAD, 0xFF, (g.sz * ((long)S->D + 2) + 8) * sizeof(T), S->stream));
+            if (reach >= S->D)
+                rc = S->comm.all_gather_planes(S->stream, src, gathered, g, S->D, sizeof(T));
+            else
+                rc = S->comm.gather_window(S->stream, src, gathered, g, S->D, sizeof(T), reach);
+            if (rc) return fail(FS_ECOMM, "gather of the advection source failed: %s", S->comm.last_error());
             src = gathered;
             zshift = (long)sc.zoff * g.sz;
         }
@@ -581,12 +596,14 @@ struct Engine : EngineBase {
         return FS_OK;
     }
 
-    int stats(int which, double* out3) override
+    int stats(int which, double* out3) override { return stats_of(arr[slot[which]], out3); }
+
+    int stats_of(const T* field, double* out3)
     {
         // whole padded array (simulation.cpp:76, :82-89); a slab counts its own planes plus
         // the physical ghost planes it holds, and the partial results are all-reduced
         const int zlo = sc.lo_wall ? 0 : 1, zhi = sc.hi_wall ? g.D + 1 : g.D;
-        fs::launch_stats<T>(S->stream, g, arr[slot[which]], red + 3 * 1024, red, 3 * 1024, zlo, zhi);
+        fs::launch_stats<T>(S->stream, g, field, red + 3 * 1024, red, 3 * 1024, zlo, zhi);
         if (S->comm.active() && S->comm.reduce_stats(S->stream, red + 3 * 1024, g, S->D))
             return fail(FS_ECOMM, "stats all-reduce failed: %s", S->comm.last_error());
         HIP_TRY(hipMemcpyAsync(out3, red + 3 * 1024, 3 * sizeof(double), hipMemcpyDeviceToHost, S->stream));
@@ -793,6 +810,8 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         s->profile = (v != "0");
     } else if (k == "elide_dead_density_solve") {
         s->elide_dead = (v != "0");
+    } else if (k == "debug_poison_gather") {
+        s->debug_poison = (v != "0");
     } else if (k == "sweep_ry") {
         int r = atoi(value);
         if (r != 2 && r != 4 && r != 8) return fail(FS_EINVAL, "sweep_ry: 2 | 4 | 8");
@@ -825,6 +844,7 @@ int fs_get_int(fs_sim* s, const char* name, int* out)
     else if (n == "speed") *out = s->speed; else if (n == "acc") *out = s->acc; else if (n == "iter") *out = s->iter;
     else if (n == "local_depth") *out = s->comm.active() ? s->comm.local_depth(s->D) : s->D;
     else if (n == "z_offset") *out = s->comm.active() ? s->comm.z_offset(s->D) : 0;
+    else if (n == "last_advect_reach") *out = s->last_reach;
     else return fail(FS_EINVAL, "unknown int member '%s'", name);
     return FS_OK;
 }

@@ -23,7 +23,7 @@ def main():
     W, H, D, acc, steps = (int(v) for v in sys.argv[5:10])
     stl = sys.argv[10] if len(sys.argv) > 10 else ""
     sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_dir=os.path.join(outdir, "data"), dump_every=1,
-                       voxel_seed=77)
+                       voxel_seed=77, debug_poison_gather=1)
     if nranks > 1:
         sim.comm_init(rank, nranks, open(idfile, "rb").read())
     Dl, zoff = sim.local_depth, sim.z_offset
@@ -35,7 +35,8 @@ def main():
     sim.run()
     out = {F.FIELD_NAMES[f]: sim.get(f) for f in (F.DENS, F.VX, F.VY, F.VZ, F.OBS, F.PRESSURE)}
     stats = np.array(sim.stats(F.DENS) + sim.stats(F.VX))
-    np.savez(os.path.join(outdir, "rank%d.npz" % rank), zoff=zoff, stats=stats, **out)
+    reach = sim._geti("last_advect_reach")
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), zoff=zoff, stats=stats, reach=reach, **out)
     sim.close()
 
 

@@ -50,6 +50,8 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks):
             if k != "pressure":
                 # halo planes hold the neighbour's boundary planes after the last exchange
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (r, k, "halo")
+        # the advection source was fetched through the velocity-bounded window (poisoned outside)
+        assert 2 <= int(z["reach"]) < D
         # sum/min/max are all-reduced: every rank reports the global values (sum up to rounding order)
         assert np.allclose(z["stats"], ref["stats"], rtol=1e-12, atol=1e-12)
     # frame dumps: ranks wrote their planes at their own offsets of the same five files
