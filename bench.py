@@ -177,7 +177,7 @@ def main():
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "sweep_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and args.precision == "fp32":
         try:
             with open(tpath) as f:
                 traffic = json.load(f).get(name, {}).get(kernel, {}).get("hbm_bytes_per_launch")
