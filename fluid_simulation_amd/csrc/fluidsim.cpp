@@ -87,6 +87,7 @@ struct fs_sim {
     int dump_every = 1;
     unsigned voxel_seed = 1;
     bool quiet = false, profile = false, elide_dead = false;
+    bool overlap = true;         // z-slabs: exchange boundary planes while the interior is computed
     bool debug_poison = false;   // fill the gathered advection source with NaN bit patterns before each gather
     int last_reach = 0;          // planes of reach used by the most recent slab advection
     // device
@@ -171,6 +172,8 @@ struct Engine : EngineBase {
     void* pinned = nullptr;             // host staging for dumps
     T* gathered = nullptr;              // all-gathered advection source (z-slabs only), LEAD-shifted
     double* red = nullptr;              // stats scratch
+    hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
+    hipEvent_t ev_edges = nullptr, ev_halo = nullptr;
     static constexpr int NRED = 3 * 1024 + 3;
 
     explicit Engine(fs_sim* s) : S(s) {}
@@ -205,6 +208,13 @@ struct Engine : EngineBase {
         flags = fb + g.lead;
         HIP_TRY(hipMalloc(&dense, dense_cells() * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&red, NRED * sizeof(double)));
+        if (cm.active()) {
+            int lo_pri = 0, hi_pri = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+            HIP_TRY(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, hi_pri));
+            HIP_TRY(hipEventCreateWithFlags(&ev_edges, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+        }
         return FS_OK;
     }
 
@@ -217,6 +227,9 @@ struct Engine : EngineBase {
         if (dense) hipFree(dense);
         if (pinned) hipHostFree(pinned);
         if (red) hipFree(red);
+        if (ev_edges) hipEventDestroy(ev_edges);
+        if (ev_halo) hipEventDestroy(ev_halo);
+        if (comm_stream) hipStreamDestroy(comm_stream);
     }
 
     // ---- array pool ------------------------------------------------------------------
@@ -321,17 +334,39 @@ struct Engine : EngineBase {
         for (int it = 0; it < sweeps; ++it) {
             int dst = acquire(src, rhs);
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
-            if (pairs && it + 1 < sweeps) {
-                // two sweeps per pass over memory; timed as its own family, one launch each
-                ScopedSpan sp(S, FAM_PAIR);
-                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c);
-                ++it;
+            const bool two = pairs && it + 1 < sweeps;   // two sweeps per pass over memory
+            auto run = [&](hipStream_t st, int zf, int zl) {
+                if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c, zf, zl);
+                else fs::launch_jacobi<T>(st, g, sc, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c, zf, zl);
+            };
+            const int e = g.zh;                          // planes a neighbour needs from each boundary
+            if (S->comm.active() && S->overlap && g.D >= 2 * e + 8) {
+                // Boundary planes first; their exchange then travels on the communication stream
+                // while the interior planes are computed.
+                const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
+                {
+                    ScopedSpan sp(S, two ? FAM_PAIR : FAM_SWEEP);
+                    if (!sc.lo_wall) run(S->stream, 1, e);
+                    if (!sc.hi_wall) run(S->stream, g.D - e + 1, g.D);
+                    HIP_TRY(hipEventRecord(ev_edges, S->stream));
+                    run(S->stream, in_lo, in_hi);
+                }
+                HIP_TRY(hipStreamWaitEvent(comm_stream, ev_edges, 0));
+                {
+                    int rc = S->comm.exchange_halo(comm_stream, arr[dst], g, sizeof(T), S->D, g.zh);
+                    if (rc) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
+                }
+                HIP_TRY(hipEventRecord(ev_halo, comm_stream));
+                HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
             } else {
-                ScopedSpan sp(S, FAM_SWEEP);
-                fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c, 1, g.D);
+                {
+                    ScopedSpan sp(S, two ? FAM_PAIR : FAM_SWEEP);
+                    run(S->stream, 1, g.D);
+                }
+                int rc = halo(arr[dst]);
+                if (rc) return rc;
             }
-            int rc = halo(arr[dst]);
-            if (rc) return rc;
+            if (two) ++it;
             if (src_temp) held[src] = false;
             src = dst;
             src_temp = true;
@@ -690,7 +725,7 @@ struct Engine : EngineBase {
         const bool pairs = fs::pair_supported<T>(g, sc);
         for (int r = 0; r < reps; ++r) {
             if (pairs && r + 1 < reps) {
-                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c);
+                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c, 1, g.D);
                 ++r;
             } else {
                 fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c, 1, g.D);
@@ -810,6 +845,8 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         s->profile = (v != "0");
     } else if (k == "elide_dead_density_solve") {
         s->elide_dead = (v != "0");
+    } else if (k == "overlap") {
+        s->overlap = (v != "0");
     } else if (k == "debug_poison_gather") {
         s->debug_poison = (v != "0");
     } else if (k == "sweep_ry") {

@@ -284,7 +284,8 @@ template <class T, int NXW, int NYW>
 __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                                      const T* __restrict__ rhs, T* __restrict__ dst,
                                                                      const uint8_t* __restrict__ flags, int b, T a,
-                                                                     T inv_c, int zc_len, int nbands, int nblk)
+                                                                     T inv_c, int z_first, int z_last, int zc_len,
+                                                                     int nbands, int nblk)
 {
     constexpr int RY = 2, BY = NYW * RY, TW = NXW * 256 + 8;
     // ring of four level-1 plane tiles (plane z lives in slot z & 3); column index = x + 3
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
     const int ty0 = wy * RY, y0 = s + ty0;
     const int x0 = 1 + wx * 256 + lane * 4;
     const bool lane_on = x0 <= W;
-    const int zbeg = 1 + zc * zc_len, zend = min(D, zbeg + zc_len - 1);   // level-2 output planes
+    const int zbeg = z_first + zc * zc_len, zend = min(z_last, zbeg + zc_len - 1);   // level-2 output planes
     if (zbeg > zend) return;                             // block-uniform
     // level-1 planes: one beyond the output chunk on each side; beyond a physical wall there is
     // no such plane (its level-1 ghost is derived below), beyond a slab boundary it is the
@@ -510,29 +511,31 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 
 template <class T, int NXW, int NYW>
 static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                          const uint8_t* flags, int b, T a, T inv_c)
+                          const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last)
 {
     constexpr int BY = NYW * 2;
     const SweepTune& tune = sweep_tune();
+    const int planes = z_last - z_first + 1;
+    if (planes <= 0) return;
     const int nbands = (g.H + (BY - 2) - 1) / (BY - 2);
     // z chunks: each re-reads 4 level-0 planes and recomputes 2 level-1 planes, so keep them
-    // long; pick the count that fills the CUs most evenly (one or two blocks per CU)
+    // long; pick the count that fills the CUs most evenly (one workgroup per CU)
     int best_nzc = 1;
     double best = -1.0;
-    const int slots = 256;   // one workgroup per CU (VGPR-limited)
-    for (int nzc = 1; nzc <= 64 && g.D / nzc >= 12; ++nzc) {
+    const int slots = 256;
+    for (int nzc = 1; nzc <= 64 && planes / nzc >= 12; ++nzc) {
         const long blocks = (long)nbands * nzc;
         const long rounds = (blocks + slots - 1) / slots;
-        const int len = (g.D + nzc - 1) / nzc;
+        const int len = (planes + nzc - 1) / nzc;
         const double eff = (double)blocks / (double)(rounds * slots) * (double)len / (double)(len + 3);
         if (eff > best + 1e-9) { best = eff; best_nzc = nzc; }
     }
-    int zc_len = (g.D + best_nzc - 1) / best_nzc;
-    if (tune.pair_zc > 0) zc_len = tune.pair_zc < g.D ? tune.pair_zc : g.D;
-    const int nzc = (g.D + zc_len - 1) / zc_len;
+    int zc_len = (planes + best_nzc - 1) / best_nzc;
+    if (tune.pair_zc > 0) zc_len = tune.pair_zc < planes ? tune.pair_zc : planes;
+    const int nzc = (planes + zc_len - 1) / zc_len;
     const int nblk = nbands * nzc;
     hipLaunchKernelGGL((jacobi_pair_kernel<T, NXW, NYW>), dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, sc, src, rhs,
-                       dst, flags, b, a, inv_c, zc_len, nbands, nblk);
+                       dst, flags, b, a, inv_c, z_first, z_last, zc_len, nbands, nblk);
 }
 
 template <class T>
@@ -546,11 +549,11 @@ template bool pair_supported<double>(const GridDesc&, const SlabCtx&);
 
 template <>
 void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const float* src, const float* rhs,
-                               float* dst, const uint8_t* flags, int b, float a, float inv_c)
+                               float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first, int z_last)
 {
     const int nxw = (g.W + 255) / 256;
     const int shape = sweep_tune().pair_small;   // 0 = default (768 threads: 12 waves at <=168 VGPRs, one block per CU)
-#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c)
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
@@ -559,13 +562,14 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
 }
 template <>
 void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const double* src,
-                                const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c)
+                                const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
+                                int z_first, int z_last)
 {
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
-    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c);
-    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c);
-    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c);
-    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c);
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last);
+    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last);
 }
 
 // =====================================================================================

@@ -30,9 +30,11 @@ def run_ranks(tmp, nranks, args):
     return out
 
 
-@pytest.mark.parametrize("nranks", [2, 4])
-def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks):
-    W, H, D, acc, steps = 20, 12, 16, 5, 3
+@pytest.mark.parametrize("nranks,D", [(2, 16), (4, 16), (2, 32), (3, 48)])
+def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D):
+    # local depth 16 (D=32 and D=48 cases) is deep enough for the boundary-first split that
+    # overlaps the halo exchange with interior compute; depth 8 and 4 take the plain path
+    W, H, acc, steps = 20, 12, 5, 3
     args = [W, H, D, acc, steps, os.path.join(GOLDEN, "sphere_24x12.stl")]
     ref_dir = run_ranks(str(tmp_path), 1, args)
     par_dir = run_ranks(str(tmp_path), nranks, args)
