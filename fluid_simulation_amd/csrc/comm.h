@@ -7,8 +7,8 @@
 // solver's own stream (no host synchronisation inside the sweep loop).
 //
 // RCCL is loaded lazily with dlopen so that single-GPU users never map the 570 MB
-// library; if the host process (e.g. torch.distributed) already mapped an RCCL, that
-// instance is reused.
+// library.  It is taken from the directory of the HIP runtime this library is bound to (see
+// RcclApi::get), so a PyTorch process and a plain process each get a consistent pair.
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>   // types and enums only; no link-time dependency
@@ -49,9 +49,21 @@ struct RcclApi {
     {
         static RcclApi api;
         if (api.lib) return api;
+        // Load the RCCL that sits next to the HIP runtime this library is actually bound to.  A
+        // process that imported PyTorch first runs on PyTorch's bundled libamdhip64 (same soname
+        // as ROCm's) and must then use PyTorch's bundled RCCL; a plain process uses /opt/rocm's.
+        // Mixing an RCCL with the other HIP runtime instance would hand it foreign streams.
+        std::string dir;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            dir = info.dli_fname;
+            size_t slash = dir.rfind('/');
+            dir = (slash == std::string::npos) ? std::string() : dir.substr(0, slash + 1);
+        }
         const char* names[] = { "librccl.so.1", "librccl.so" };
-        for (const char* n : names)
-            if ((api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!dir.empty())
+            for (const char* n : names)
+                if ((api.lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL))) break;
         if (!api.lib)
             for (const char* n : names)
                 if ((api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
