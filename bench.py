@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "shm"],
+                    help="shm: development rehearsal of the N>1 path on fewer GPUs than ranks (host-staged "
+                         "halo planes through shared memory, torch.distributed over gloo); never a result")
     args = ap.parse_args()
 
     import torch
@@ -109,10 +112,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); the solver has no CPU path")
+    rehearsal = args.transport == "shm"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    ctl_device = None if rehearsal else torch.device("cuda", local_rank)   # where control-plane tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import fluid_simulation_amd as F
 
@@ -132,7 +142,7 @@ def main():
     sim = F.Simulation(W, H, D, args.steps, acc=acc, precision=args.precision, quiet=1, dump_every=0, profile=1)
     if world > 1:
         from fluid_simulation_amd import dist as fsdist
-        uid = fsdist.share_unique_id(dist, F.comm_unique_id, rank, device=torch.device("cuda", local_rank))
+        uid = fsdist.share_unique_id(dist, lambda: F.comm_unique_id(args.transport), rank, device=ctl_device)
         sim.comm_init(rank, world, uid)
     with tempfile.TemporaryDirectory() as tmp:
         added = add_obstacles(F, sim, cfg, tmp)
@@ -149,7 +159,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        elapsed = fsdist.max_over_ranks(dist, elapsed, device=torch.device("cuda", local_rank))
+        elapsed = fsdist.max_over_ranks(dist, elapsed, device=ctl_device)
 
     # dominant kernel: the solver sweep, HIP events on the solver's own stream over the timed
     # region.  Single GPU runs it as jacobi_pair_kernel (two iterations per launch, temporal
@@ -201,7 +211,8 @@ def main():
             "workload": "%s: %dx%dx%d wind tunnel, %s, %d solver iterations per solve, Jacobi, dumps off"
                         % (name, W, H, D, "sphere + plate STL obstacles" if cfg["plate"] else "sphere STL obstacle", acc),
             "grid": [W, H, D], "acc": acc, "solver": "jacobi",
-            "parallelism": "z-slabs x%d, RCCL halo exchange" % world if world > 1 else "single GPU",
+            "parallelism": ("z-slabs x%d, %s" % (world, "REHEARSAL over host shared memory (not a result)" if rehearsal
+                                                  else "RCCL halo exchange over xGMI")) if world > 1 else "single GPU",
             "voxelizer_points_added": added,
         },
         "jacobi_iter_per_sec": iters_per_sec,
