@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "voxelize.h"
 #include "comm.h"
+#include "dump.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -106,6 +107,8 @@ struct fs_sim {
     bool dump_open = false, dump_warned = false, in_run = false;
     long step_no = 0;
     long dump_frames = 0;
+    fs::FrameWriter writer;      // pinned double-buffered D2H + writer thread
+    bool dump_async = true;
 
     int span_begin(int fam)
     {
@@ -651,8 +654,6 @@ struct Engine : EngineBase {
     {
         static const char* const names[5] = { "data.bin", "obs.bin", "v_x.bin", "v_y.bin", "v_z.bin" };
         static const int which[5] = { FS_DENS, FS_OBS, FS_VX, FS_VY, FS_VZ };
-        const long cells = dense_cells();
-        if (!pinned) HIP_TRY(hipHostMalloc(&pinned, cells * sizeof(float), hipHostMallocDefault));
         if (!S->dump_open) {
             // rank 0 truncates like the reference's ofstream::open (simulation.cpp:56-60); the other
             // slab ranks open the same files for update once they exist
@@ -689,19 +690,19 @@ struct Engine : EngineBase {
         const int zlo = sc.lo_wall ? 0 : 1, zhi = sc.hi_wall ? g.D + 1 : g.D;
         const long plane = (long)(g.W + 2) * (g.H + 2);
         const long frame_cells = plane * ((long)S->D + 2);
-        for (int k = 0; k < 5; ++k) {
-            fs::launch_pack<T, float>(S->stream, g, arr[slot[which[k]]], (float*)dense, zlo, zhi);
-            const long nloc = plane * (zhi - zlo + 1);
-            HIP_TRY(hipMemcpyAsync(pinned, dense, nloc * sizeof(float), hipMemcpyDeviceToHost, S->stream));
-            HIP_TRY(hipStreamSynchronize(S->stream));
-            if (S->comm.active()) {
-                long off = (S->dump_frames * frame_cells + plane * (long)(sc.zoff + zlo)) * (long)sizeof(float);
-                fseek(S->dump_fp[k], off, SEEK_SET);
-            }
-            if (fwrite(pinned, sizeof(float), nloc, S->dump_fp[k]) != (size_t)nloc)
-                return fail(FS_EIO, "short write to %s/%s", S->dump_dir.c_str(), names[k]);
-        }
+        const long nloc = plane * (zhi - zlo + 1);
+        std::string werr;
+        if (S->writer.init(S->device, nloc * 5, S->dump_fp, &werr)) return fail(FS_EHIP, "frame writer: %s", werr.c_str());
+        const int k = (int)(S->dump_frames % fs::FrameWriter::NSLOT);
+        if (S->writer.acquire(k, &werr)) return fail(FS_EIO, "%s (%s)", werr.c_str(), S->dump_dir.c_str());
+        for (int f = 0; f < 5; ++f)
+            fs::launch_pack<T, float>(S->stream, g, arr[slot[which[f]]], S->writer.dev[k] + (size_t)f * nloc, zlo, zhi);
+        const long off = S->comm.active()
+                             ? (S->dump_frames * frame_cells + plane * (long)(sc.zoff + zlo)) * (long)sizeof(float)
+                             : -1;
+        if (S->writer.submit(k, S->stream, nloc, off, &werr)) return fail(FS_EHIP, "frame writer: %s", werr.c_str());
         S->dump_frames++;
+        if (!S->dump_async && S->writer.flush(&werr)) return fail(FS_EIO, "%s (%s)", werr.c_str(), S->dump_dir.c_str());
         return FS_OK;
     }
 
@@ -811,6 +812,11 @@ int fs_destroy(fs_sim* s)
     if (s->stream) hipStreamSynchronize(s->stream);
     s->resolve_spans();
     for (hipEvent_t ev : s->event_pool) hipEventDestroy(ev);
+    {
+        std::string werr;
+        s->writer.flush(&werr);
+        s->writer.shutdown();
+    }
     for (int k = 0; k < 5; ++k)
         if (s->dump_fp[k]) fclose(s->dump_fp[k]);
     delete s->eng;
@@ -845,6 +851,8 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         s->profile = (v != "0");
     } else if (k == "elide_dead_density_solve") {
         s->elide_dead = (v != "0");
+    } else if (k == "dump_async") {
+        s->dump_async = (v != "0");
     } else if (k == "overlap") {
         s->overlap = (v != "0");
     } else if (k == "debug_poison_gather") {
@@ -971,6 +979,8 @@ int fs_sync(fs_sim* s)
     if (!s) return fail(FS_EINVAL, "null handle");
     hipSetDevice(s->device);
     HIP_TRY(hipStreamSynchronize(s->stream));
+    std::string werr;
+    if (s->writer.flush(&werr)) return fail(FS_EIO, "frame writer: %s", werr.c_str());
     return FS_OK;
 }
 
@@ -980,6 +990,10 @@ int fs_run(fs_sim* s)
     const bool talk = !s->quiet && (!s->comm.active() || s->comm.rank == 0);
     if (talk) printf("starting 3-D simulation: %dx%dx%d  steps = %d\n", s->W, s->H, s->D, s->iter);   // simulation.cpp:51-53
     // run() re-opens (truncates) the five files (simulation.cpp:56-60)
+    {
+        std::string werr;
+        if (s->writer.flush(&werr)) return fail(FS_EIO, "frame writer: %s", werr.c_str());
+    }
     for (int k = 0; k < 5; ++k)
         if (s->dump_fp[k]) { fclose(s->dump_fp[k]); s->dump_fp[k] = nullptr; }
     s->dump_open = false;
@@ -996,8 +1010,10 @@ int fs_run(fs_sim* s)
     }
     if (!rc && s->dump_every == -1) rc = s->eng->dump_frame();
     s->in_run = false;
-    for (int k = 0; k < 5; ++k)
-        if (s->dump_fp[k]) fflush(s->dump_fp[k]);
+    {
+        std::string werr;
+        if (s->writer.flush(&werr) && !rc) rc = fail(FS_EIO, "frame writer: %s", werr.c_str());
+    }
     if (rc) return rc;
     static const int which[4] = { FS_DENS, FS_VX, FS_VY, FS_VZ };
     static const char* const label[4] = { "density ", "velocity x", "velocity y", "velocity z" };

@@ -76,6 +76,8 @@ int fs_destroy(fs_sim* s);
  *   "dump_dir"    directory for frame dumps, default "data" (simulation.cpp:56-60)
  *   "dump_every"  N>=1 dump every Nth step (default 1 = reference behaviour), 0 = never,
  *                 -1 = last step of fs_run only.  May be changed at any time.
+ *   "dump_async"  "1" (default): frames go through a pinned double buffer and a writer thread while
+ *                 the next step computes; "0": every dump completes before fs_step returns
  *   "voxel_seed"  seed of the voxelizer's minstd_rand stream (object_loader.cpp:399 uses a
  *                 thread-id hash; default here is 1)
  *   "quiet"       "1" suppresses the reference's console lines
