@@ -169,6 +169,7 @@ struct Engine : EngineBase {
     int slot[FS_NFIELDS];               // field -> array id (aliases allowed inside a step)
     bool held[NPOOL] = {false};         // temporaries owned by a running solve
     uint8_t* flags = nullptr;           // shifted like the fields
+    uint8_t* kill = nullptr;            // one byte per four cells for the sweeps; byte (cell+3)/4
     bool flags_dirty = true;
     bool halos_dirty = false;           // a host-side mutation may have changed a slab boundary plane
     void* dense = nullptr;              // device staging for pack/unpack: dense local slab, sizeof(double) per cell
@@ -209,6 +210,10 @@ struct Engine : EngineBase {
         HIP_TRY(hipMalloc((void**)&fb, g.n));
         HIP_TRY(hipMemsetAsync(fb, 0, g.n, S->stream));
         flags = fb + g.lead;
+        uint8_t* kb = nullptr;
+        HIP_TRY(hipMalloc((void**)&kb, g.n / 4 + 16));
+        HIP_TRY(hipMemsetAsync(kb, 0, g.n / 4 + 16, S->stream));
+        kill = kb + (g.lead - fs::LEAD) / 4;
         HIP_TRY(hipMalloc(&dense, dense_cells() * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&red, NRED * sizeof(double)));
         if (cm.active()) {
@@ -226,6 +231,7 @@ struct Engine : EngineBase {
         for (int i = 0; i < NPOOL; ++i)
             if (arr[i]) hipFree(arr[i] - g.lead);
         if (flags) hipFree(flags - g.lead);
+        if (kill) hipFree(kill - (g.lead - fs::LEAD) / 4);
         if (gathered) hipFree(gathered - fs::LEAD);   // global array with one ghost plane per side
         if (dense) hipFree(dense);
         if (pinned) hipHostFree(pinned);
@@ -297,6 +303,7 @@ struct Engine : EngineBase {
         }
         ScopedSpan sp(S, FAM_MISC);
         fs::launch_build_flags<T>(S->stream, g, sc, arr[slot[FS_OBS]], flags);
+        fs::launch_build_kill(S->stream, g, sc, flags, kill);
         flags_dirty = false;
         return FS_OK;
     }
@@ -339,8 +346,8 @@ struct Engine : EngineBase {
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
             const bool two = pairs && it + 1 < sweeps;   // two sweeps per pass over memory
             auto run = [&](hipStream_t st, int zf, int zl) {
-                if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c, zf, zl);
-                else fs::launch_jacobi<T>(st, g, sc, arr[src], arr[rhs], arr[dst], flags, b, a, inv_c, zf, zl);
+                if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl);
+                else fs::launch_jacobi<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl);
             };
             const int e = g.zh;                          // planes a neighbour needs from each boundary
             if (S->comm.active() && S->overlap && g.D >= 2 * e + 8) {
@@ -720,16 +727,16 @@ struct Engine : EngineBase {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         // one untimed sweep to fault in code and scratch
-        fs::launch_jacobi<T>(S->stream, g, sc, arr[slot[field]], arr[slot[prev]], arr[s1], flags, b, (T)a, inv_c, 1, g.D);
+        fs::launch_jacobi<T>(S->stream, g, sc, arr[slot[field]], arr[slot[prev]], arr[s1], kill, b, (T)a, inv_c, 1, g.D);
         HIP_TRY(hipEventRecord(e0, S->stream));
         int src = s1, dst = s2;
         const bool pairs = fs::pair_supported<T>(g, sc);
         for (int r = 0; r < reps; ++r) {
             if (pairs && r + 1 < reps) {
-                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c, 1, g.D);
+                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D);
                 ++r;
             } else {
-                fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], flags, b, (T)a, inv_c, 1, g.D);
+                fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D);
             }
             int t = src; src = dst; dst = t;
         }

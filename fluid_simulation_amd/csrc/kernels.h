@@ -50,9 +50,10 @@ struct SweepTune {
 };
 SweepTune& sweep_tune();
 
+// NOTE: the sweep launchers take the KILL-byte array (launch_build_kill), not the flag bytes.
 template <class T>
 void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                   const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last);
+                   const uint8_t* kill, int b, T a, T inv_c, int z_first, int z_last);
 
 // Two sweeps in one pass (temporal blocking); same result as two launch_jacobi calls.
 // Needs W <= 1024; on a z-slab additionally two halo planes per side (g.zh == 2), current in
@@ -86,6 +87,10 @@ void launch_advect(hipStream_t st, const GridDesc& g, const SlabCtx& sc, int b, 
 
 template <class T>
 void launch_build_flags(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* obs, uint8_t* flags);
+
+// one kill byte per four cells for the sweep kernels (see kernels.hip); `kill` is shifted so
+// that byte (cell + 3) / 4 belongs to the lane group starting at `cell`
+void launch_build_kill(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, uint8_t* kill);
 
 template <class T>
 void launch_inlet_velocity(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz, T speed);

@@ -55,7 +55,7 @@ struct PlaneIn {
 template <class T, int RY>
 struct AuxIn {
     T rhs[RY][4];
-    unsigned fl[RY];     // four flag bytes per row
+    unsigned fl[RY];     // kill byte of the lane's four cells: bits 0-3 solid, bits 4-7 solid-or-near
 };
 
 template <class T, int RY, int ABL>
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
     const bool full_group = (x0 + 3 <= W);
     const bool edge_l = lane_on && (lane == 0);                                   // x0-1 comes from memory
     const bool edge_r = lane_on && full_group && ((lane == 63) || (x0 + 4 > W));  // x0+4 comes from memory
-    const unsigned zero_bits = (b == 0) ? F_SOLID : (F_SOLID | F_NEAR);
+    const int kill_shift = (b == 0) ? 0 : 4;             // which nibble of the kill byte applies (simulation.cpp:222 vs :240)
     const T zero = (T)0;
     const long row0 = cell(g, x0, y0, 0);                // lane's first cell in plane 0
 
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
         for (int r = 0; r < RY; ++r) {
             const bool on = lane_on && (y0 + r <= H);
             ld4(rhs + off + r * g.sy, on && !(ABL & 4), X.rhs[r]);
-            X.fl[r] = (on && !(ABL & 1)) ? *reinterpret_cast<const unsigned*>(flags + off + r * g.sy) : 0u;
+            X.fl[r] = (on && !(ABL & 1)) ? (unsigned)flags[(off + r * g.sy + 3) >> 2] : 0u;
         }
     };
 
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int x = x0 + e;
-                    const bool kill = ((fl >> (8 * e)) & zero_bits) != 0;
+                    const bool kill = ((fl >> (e + kill_shift)) & 1u) != 0;
                     T ghost_src = (e > 0) ? u[e - 1] : zero;
                     // cells past W: the outflow ghost copies u(W) (:191); row padding stays 0
                     st.e[e] = (x <= W) ? (kill ? zero : u[e]) : ((x == W + 1) ? ghost_src : zero);
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
     const bool full_group = (x0 + 3 <= W);
     const bool edge_l = lane_on && (lane == 0);
     const bool edge_r = lane_on && full_group && ((lane == 63) || (x0 + 4 > W));
-    const unsigned zero_bits = (b == 0) ? F_SOLID : (F_SOLID | F_NEAR);
+    const int kill_shift = (b == 0) ? 0 : 4;
     const T zero = (T)0;
     const long row0 = cell(g, x0, y0, 0);
 
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
         for (int r = 0; r < RY; ++r) {
             const bool on = lane_on && (y0 + r >= 1) && (y0 + r <= H);
             ld4(rhs + off + r * g.sy, on, X.rhs[r]);
-            X.fl[r] = on ? *reinterpret_cast<const unsigned*>(flags + off + r * g.sy) : 0u;
+            X.fl[r] = on ? (unsigned)flags[(off + r * g.sy + 3) >> 2] : 0u;
         }
     };
 
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int x = x0 + e;
-            const bool kill = ((fl >> (8 * e)) & zero_bits) != 0;
+            const bool kill = ((fl >> (e + kill_shift)) & 1u) != 0;
             T ghost_src = (e > 0) ? u[e - 1] : zero;
             st[e] = (x <= W) ? (kill ? zero : u[e]) : ((x == W + 1) ? ghost_src : zero);
         }
@@ -930,6 +930,35 @@ void launch_build_flags(hipStream_t st, const GridDesc& g, const SlabCtx& sc, co
 }
 template void launch_build_flags<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, uint8_t*);
 template void launch_build_flags<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, uint8_t*);
+
+// Kill bytes for the sweep kernels: one byte per lane group (four x-consecutive cells starting at
+// x = 1 mod 4), bits 0-3 = solid, bits 4-7 = solid or next to a solid; byte index = (cell + 3) / 4.
+// A quarter of the flag traffic, and the sweeps need nothing else of the flags.
+__global__ void build_kill_kernel(GridDesc g, const uint8_t* __restrict__ flags, uint8_t* __restrict__ kill, int zlo)
+{
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x;            // group index along x
+    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = zlo + blockIdx.z;
+    const int x0 = 1 + 4 * gx;
+    if (x0 > g.W || y > g.H) return;
+    const long c = cell(g, x0, y, z);
+    const unsigned f = *reinterpret_cast<const unsigned*>(flags + c);
+    unsigned out = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned fe = (f >> (8 * e)) & 0xffu;
+        if (fe & F_SOLID) out |= 1u << e;
+        if (fe & (F_SOLID | F_NEAR)) out |= 16u << e;
+    }
+    kill[(c + 3) >> 2] = (uint8_t)out;
+}
+void launch_build_kill(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, uint8_t* kill)
+{
+    const int zlo = (g.zh >= 2 && !sc.lo_wall) ? 0 : 1, zhi = (g.zh >= 2 && !sc.hi_wall) ? g.D + 1 : g.D;
+    const int ng = (g.W + 3) / 4;
+    hipLaunchKernelGGL(build_kill_kernel, dim3((ng + 63) / 64, (g.H + 3) / 4, zhi - zlo + 1), dim3(64, 4, 1), 0, st, g,
+                       flags, kill, zlo);
+}
 
 // =====================================================================================
 // Inlet forcing: velocity (speed,0,0) on the x=1 face (simulation.cpp:103-105) and
