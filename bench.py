@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "shm"],
                     help="shm: development rehearsal of the N>1 path on fewer GPUs than ranks (host-staged "
                          "halo planes through shared memory, torch.distributed over gloo); never a result")
@@ -256,7 +257,7 @@ def main():
         s2.close()
 
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(acc)
+        out["cpu_baseline"] = cpu_baseline(acc, budget_s=args.cpu_budget)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

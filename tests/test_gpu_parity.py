@@ -382,3 +382,27 @@ def test_simulation_out_reference_defaults(tmp_path):
     vx = np.fromfile(str(tmp_path / "data" / "v_x.bin"), dtype=np.float32).reshape(2, 66, 66, 130)
     assert np.isfinite(vx).all() and vx[-1].max() > 1.0
     assert not np.fromfile(str(tmp_path / "data" / "obs.bin"), dtype=np.float32).any()
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--steps", "1", "--warmup", "1",
+                          "--cpu-budget", "1.0"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["config"]["workload"].startswith("c2") and d["value"] > 1e8
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 1000.0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "64x64x64" in c["sample"]
