@@ -878,6 +878,10 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         int f = atoi(value);
         if (f != 1 && f != 2) return fail(FS_EINVAL, "sweep_fuse: 1 | 2");
         fs::sweep_tune().fuse = f;
+    } else if (k == "project_kernels") {
+        if (v == "cell") fs::sweep_tune().project_cell = 1;
+        else if (v == "march") fs::sweep_tune().project_cell = 0;
+        else return fail(FS_EINVAL, "project_kernels: march | cell");
     } else if (k == "pair_zc") {
         fs::sweep_tune().pair_zc = atoi(value);
     } else if (k == "pair_small") {

@@ -46,6 +46,7 @@ struct SweepTune {
     int abl = 0;
     int fuse = 2;             // sweeps fused per pass over memory (1 = never fuse, 2 = pair kernel)
     int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic
+    int project_cell = 0;     // 1 = per-cell divergence/gradient kernels instead of the z-marching ones
     int pair_small = 0;       // pair-kernel workgroup shape: 0 = 12 waves (default), 1 = 8 waves, 3 = 16 waves
 };
 SweepTune& sweep_tune();

@@ -649,6 +649,245 @@ template void launch_gs_lex<float>(hipStream_t, const GridDesc&, float*, const f
 template void launch_gs_lex<double>(hipStream_t, const GridDesc&, double*, const double*, const uint8_t*, int, double,
                                     double, int);
 
+template <class T>
+__device__ __forceinline__ T one_sided_grad(bool fp, bool fm, T pp, T pc, T pm, T h, T two_h);
+
+// =====================================================================================
+// z-marching forms of the two projection passes.  Same wave decomposition as the sweep
+// (256 x-consecutive cells x RY rows per wave, 16 B per lane, XCD-contiguous tiles): the
+// planes z-1 / z+1 a cell needs stay in registers while the wave walks along z, rows y-1 /
+// y+1 are L1/L2 hits, x neighbours cross lanes by shuffle, so every input array is read from
+// HBM once.  Arithmetic and pass order are those of the per-cell kernels below, which remain
+// as the plain statement (and serve fs_set_option "project_kernels"="cell").
+// =====================================================================================
+template <class T>
+struct MarchTile {
+    int lane, x0, y0, zbeg, zend;
+    bool lane_on, full_group, edge_l, edge_r, live;
+    long row0;
+};
+template <class T, int RY>
+__device__ __forceinline__ MarchTile<T> march_tile(const GridDesc& g, int zc_len, int nxw, int nybg, int nblk)
+{
+    MarchTile<T> t;
+    const int v = xcd_contiguous(blockIdx.x, nblk);
+    const int xw = v % nxw, ybg = (v / nxw) % nybg, zc = v / (nxw * nybg);
+    t.lane = threadIdx.x & 63;
+    t.y0 = 1 + (ybg * 4 + (threadIdx.x >> 6)) * RY;
+    t.x0 = 1 + xw * 256 + t.lane * 4;
+    t.lane_on = t.x0 <= g.W;
+    t.zbeg = 1 + zc * zc_len;
+    t.zend = min(g.D, t.zbeg + zc_len - 1);
+    t.full_group = (t.x0 + 3 <= g.W);
+    t.edge_l = t.lane_on && (t.lane == 0);
+    t.edge_r = t.lane_on && t.full_group && ((t.lane == 63) || (t.x0 + 4 > g.W));
+    t.live = (t.y0 <= g.H) && (t.zbeg <= t.zend);
+    t.row0 = cell(g, t.x0, t.y0, 0);
+    return t;
+}
+template <class T>
+__device__ __forceinline__ void ld_row(const T* ptr, bool on, T (&out)[4])
+{
+    V4<T> q = {{(T)0, (T)0, (T)0, (T)0}};
+    if (on) q = *reinterpret_cast<const V4<T>*>(ptr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = q.e[e];
+}
+// Store the lane's four cells of an interior row of a field with boundary code b, the way
+// setBounds leaves them (simulation.cpp:183-246): `u` un-zeroed values, `killmask` bit e set =>
+// cell e is zeroed; ghost faces determined by this row are written from the un-zeroed values.
+template <class T>
+__device__ __forceinline__ void store_row_bounds(const GridDesc& g, const SlabCtx& sc, T* dst, long base, int x0, int y, int z,
+                                                 const T (&u)[4], unsigned killmask, int b)
+{
+    const T zero = (T)0;
+    V4<T> st;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int x = x0 + e;
+        T ghost_src = (e > 0) ? u[e - 1] : zero;
+        st.e[e] = (x <= g.W) ? (((killmask >> e) & 1u) ? zero : u[e]) : ((x == g.W + 1) ? ghost_src : zero);
+    }
+    *reinterpret_cast<V4<T>*>(dst + base) = st;
+    if (x0 == 1) dst[base - 1] = (b == 1) ? -u[0] : u[0];
+    if (x0 + 3 == g.W) dst[base + 4] = u[3];
+    const bool zlo = (z == 1) && sc.lo_wall, zhi = (z == g.D) && sc.hi_wall;
+    if (y == 1 || y == g.H || zlo || zhi) {
+        V4<T> gy, gz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = (x0 + e <= g.W);
+            gy.e[e] = in ? ((b == 2) ? -u[e] : u[e]) : zero;
+            gz.e[e] = in ? ((b == 3) ? -u[e] : u[e]) : zero;
+        }
+        if (y == 1) *reinterpret_cast<V4<T>*>(dst + base - g.sy) = gy;
+        if (y == g.H) *reinterpret_cast<V4<T>*>(dst + base + g.sy) = gy;
+        if (zlo) *reinterpret_cast<V4<T>*>(dst + base - g.sz) = gz;
+        if (zhi) *reinterpret_cast<V4<T>*>(dst + base + g.sz) = gz;
+    }
+}
+
+// divergence + pressure reset + setBounds(0,div) + setBounds(0,p)   simulation.cpp:295-319
+template <class T, int RY>
+__global__ __launch_bounds__(256) void divergence_march_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ vx,
+                                                                const T* __restrict__ vy, const T* __restrict__ vz,
+                                                                T* __restrict__ dv, T* __restrict__ p,
+                                                                const uint8_t* __restrict__ flags, T mhalf_h, int zc_len,
+                                                                int nxw, int nybg, int nblk)
+{
+    const MarchTile<T> t = march_tile<T, RY>(g, zc_len, nxw, nybg, nblk);
+    if (!t.live) return;                                 // wave-uniform
+    const int H = g.H;
+    const T zero = (T)0;
+    T zm[RY][4], zc[RY][4], zp[RY][4];                   // v_z at planes z-1, z, z+1
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const bool on = t.lane_on && (t.y0 + r <= H);
+        ld_row(vz + t.row0 + (long)(t.zbeg - 1) * g.sz + r * g.sy, on, zm[r]);
+        ld_row(vz + t.row0 + (long)t.zbeg * g.sz + r * g.sy, on, zc[r]);
+    }
+    for (int z = t.zbeg; z <= t.zend; ++z) {
+        const long off = t.row0 + (long)z * g.sz;
+        T xr[RY][4], yr[RY + 2][4];
+        unsigned fl[RY];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const bool on = t.lane_on && (t.y0 + r <= H);
+            ld_row(vz + off + g.sz + r * g.sy, on, zp[r]);
+            ld_row(vx + off + r * g.sy, on, xr[r]);
+            fl[r] = on ? *reinterpret_cast<const unsigned*>(flags + off + r * g.sy) : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < RY + 2; ++r) ld_row(vy + off + (r - 1) * g.sy, t.lane_on && (t.y0 + r - 1 <= H + 1), yr[r]);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const int y = t.y0 + r;
+            T left = __shfl_up(xr[r][3], 1);
+            T right = __shfl_down(xr[r][0], 1);
+            if (!(t.lane_on && y <= H)) continue;        // y <= H is wave-uniform; shuffles are above
+            const long base = off + r * g.sy;
+            if (t.edge_l) left = vx[base - 1];
+            if (t.edge_r) right = vx[base + 4];
+            T d[4], zeros[4] = {zero, zero, zero, zero};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned f = (fl[r] >> (8 * e)) & 0xffu;
+                T acc = zero;                            // :306-312 in this order
+                if (f & F_XP) acc += (e < 3) ? xr[r][e + 1] : right;
+                if (f & F_XM) acc -= (e > 0) ? xr[r][e - 1] : left;
+                if (f & F_YP) acc += yr[r + 2][e];
+                if (f & F_YM) acc -= yr[r][e];
+                if (f & F_ZP) acc += zp[r][e];
+                if (f & F_ZM) acc -= zm[r][e];
+                d[e] = (f & F_SOLID) ? zero : mhalf_h * acc;
+            }
+            store_row_bounds<T>(g, sc, dv, base, t.x0, y, z, d, 0u, 0);
+            store_row_bounds<T>(g, sc, p, base, t.x0, y, z, zeros, 0u, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                zm[r][e] = zc[r][e];
+                zc[r][e] = zp[r][e];
+            }
+    }
+}
+
+// v -= grad p, then setBounds(1,vx), (2,vy), (3,vz)   simulation.cpp:322-361
+template <class T, int RY>
+__global__ __launch_bounds__(256) void gradient_march_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ p,
+                                                              T* __restrict__ vx, T* __restrict__ vy, T* __restrict__ vz,
+                                                              const uint8_t* __restrict__ flags, T h, T two_h, int zc_len,
+                                                              int nxw, int nybg, int nblk)
+{
+    const MarchTile<T> t = march_tile<T, RY>(g, zc_len, nxw, nybg, nblk);
+    if (!t.live) return;
+    const int H = g.H;
+    T pm[RY][4], pc[RY][4], pp[RY][4];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const bool on = t.lane_on && (t.y0 + r <= H);
+        ld_row(p + t.row0 + (long)(t.zbeg - 1) * g.sz + r * g.sy, on, pm[r]);
+        ld_row(p + t.row0 + (long)t.zbeg * g.sz + r * g.sy, on, pc[r]);
+    }
+    for (int z = t.zbeg; z <= t.zend; ++z) {
+        const long off = t.row0 + (long)z * g.sz;
+        T hb[4], ht[4];
+        ld_row(p + off - g.sy, t.lane_on, hb);
+        ld_row(p + off + RY * g.sy, t.lane_on && (t.y0 + RY <= H + 1), ht);
+        unsigned fl[RY];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const bool on = t.lane_on && (t.y0 + r <= H);
+            ld_row(p + off + g.sz + r * g.sy, on, pp[r]);
+            fl[r] = on ? *reinterpret_cast<const unsigned*>(flags + off + r * g.sy) : 0u;
+        }
+        // in a partial band the row above the last live row is the ghost row H+1, not loaded above
+#pragma unroll
+        for (int r = 1; r < RY; ++r)
+            if (t.y0 + r == H + 1) ld_row(p + off + r * g.sy, t.lane_on, pc[r]);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const int y = t.y0 + r;
+            T left = __shfl_up(pc[r][3], 1);
+            T right = __shfl_down(pc[r][0], 1);
+            if (!(t.lane_on && y <= H)) continue;
+            const long base = off + r * g.sy;
+            if (t.edge_l) left = p[base - 1];
+            if (t.edge_r) right = p[base + 4];
+            T ux[4], uy[4], uz[4];
+            ld_row(vx + base, true, ux);
+            ld_row(vy + base, true, uy);
+            ld_row(vz + base, true, uz);
+            unsigned killmask = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned f = (fl[r] >> (8 * e)) & 0xffu;
+                if (f & (F_SOLID | F_NEAR)) killmask |= 1u << e;
+                if (!(f & F_SOLID)) {                    // :326
+                    const T c0 = pc[r][e];
+                    const T xp1 = (e < 3) ? pc[r][e + 1] : right, xm1 = (e > 0) ? pc[r][e - 1] : left;
+                    const T yp1 = (r < RY - 1) ? pc[r < RY - 1 ? r + 1 : r][e] : ht[e];
+                    const T ym1 = (r > 0) ? pc[r > 0 ? r - 1 : 0][e] : hb[e];
+                    ux[e] -= one_sided_grad<T>(f & F_XP, f & F_XM, xp1, c0, xm1, h, two_h);
+                    uy[e] -= one_sided_grad<T>(f & F_YP, f & F_YM, yp1, c0, ym1, h, two_h);
+                    uz[e] -= one_sided_grad<T>(f & F_ZP, f & F_ZM, pp[r][e], c0, pm[r][e], h, two_h);
+                }
+            }
+            store_row_bounds<T>(g, sc, vx, base, t.x0, y, z, ux, killmask, 1);
+            store_row_bounds<T>(g, sc, vy, base, t.x0, y, z, uy, killmask, 2);
+            store_row_bounds<T>(g, sc, vz, base, t.x0, y, z, uz, killmask, 3);
+        }
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pm[r][e] = pc[r][e];
+                pc[r][e] = pp[r][e];
+            }
+    }
+}
+
+struct MarchLaunch {
+    int zc_len, nxw, nybg, nblk;
+};
+static MarchLaunch march_launch(const GridDesc& g, int RY)
+{
+    MarchLaunch m;
+    m.nxw = (g.W + 255) / 256;
+    const int nyb = (g.H + RY - 1) / RY;
+    m.nybg = (nyb + 3) / 4;
+    const long per_layer = (long)m.nxw * m.nybg;
+    long want = (2048 + per_layer - 1) / per_layer;
+    if (want < 1) want = 1;
+    m.zc_len = (int)((g.D + want - 1) / want);
+    if (m.zc_len < 8) m.zc_len = g.D < 8 ? g.D : 8;
+    const int nzc = (g.D + m.zc_len - 1) / m.zc_len;
+    m.nblk = (int)(per_layer * nzc);
+    return m;
+}
+
 // =====================================================================================
 // Stand-alone setBounds (simulation.cpp:183-246): faces first, then the zeroing passes.
 // The hot kernels fuse this; the stand-alone form serves fs_set_bounds and odd callers.
@@ -763,8 +1002,15 @@ template <class T>
 void launch_divergence(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* vx, const T* vy, const T* vz,
                        T* div, T* p, const uint8_t* flags, T mhalf_h)
 {
-    hipLaunchKernelGGL((divergence_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, div, p, flags,
-                       mhalf_h);
+    if (sweep_tune().project_cell) {
+        hipLaunchKernelGGL((divergence_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, div, p, flags,
+                           mhalf_h);
+        return;
+    }
+    constexpr int RY = 2;
+    const MarchLaunch m = march_launch(g, RY);
+    hipLaunchKernelGGL((divergence_march_kernel<T, RY>), dim3(m.nblk), dim3(256), 0, st, g, sc, vx, vy, vz, div, p, flags,
+                       mhalf_h, m.zc_len, m.nxw, m.nybg, m.nblk);
 }
 template void launch_divergence<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, const float*,
                                        const float*, float*, float*, const uint8_t*, float);
@@ -815,7 +1061,14 @@ template <class T>
 void launch_gradient(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* p, T* vx, T* vy, T* vz,
                      const uint8_t* flags, T h, T two_h)
 {
-    hipLaunchKernelGGL((gradient_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, p, vx, vy, vz, flags, h, two_h);
+    if (sweep_tune().project_cell) {
+        hipLaunchKernelGGL((gradient_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, p, vx, vy, vz, flags, h, two_h);
+        return;
+    }
+    constexpr int RY = 2;
+    const MarchLaunch m = march_launch(g, RY);
+    hipLaunchKernelGGL((gradient_march_kernel<T, RY>), dim3(m.nblk), dim3(256), 0, st, g, sc, p, vx, vy, vz, flags, h, two_h,
+                       m.zc_len, m.nxw, m.nybg, m.nblk);
 }
 template void launch_gradient<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, float*, float*, float*,
                                      const uint8_t*, float, float);
