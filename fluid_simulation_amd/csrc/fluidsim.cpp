@@ -88,6 +88,7 @@ struct fs_sim {
     int dump_every = 1;
     unsigned voxel_seed = 1;
     bool quiet = false, profile = false, elide_dead = false;
+    bool fuse_advect = true;     // one kernel for the three velocity advections of a step (single GPU)
     bool overlap = true;         // z-slabs: exchange boundary planes while the interior is computed
     bool debug_poison = false;   // fill the gathered advection source with NaN bit patterns before each gather
     int last_reach = 0;          // planes of reach used by the most recent slab advection
@@ -548,8 +549,17 @@ struct Engine : EngineBase {
         for (int k = 0; k < 3; ++k)                      // :115-117
             if ((rc = diffuse_T(k + 1, V[k], V0[k]))) return rc;
         if ((rc = project())) return rc;                 // :120
-        for (int k = 0; k < 3; ++k)                      // :125-127
-            if ((rc = advect(k + 1, V[k], V0[k]))) return rc;
+        if (!S->comm.active() && S->fuse_advect && slot[FS_VX] != slot[FS_VX_PREV] && slot[FS_VY] != slot[FS_VY_PREV] &&
+            slot[FS_VZ] != slot[FS_VZ_PREV]) {
+            // :125-127 in one pass (the three traces only chain through the cell's own values)
+            ScopedSpan sp(S, FAM_ADVECT);
+            fs::launch_advect_velocity<T>(S->stream, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
+                                          arr[slot[FS_VX_PREV]], arr[slot[FS_VY_PREV]], arr[slot[FS_VZ_PREV]], flags,
+                                          (T)S->dt * (T)S->W, (T)S->dt * (T)S->H, (T)S->dt * (T)S->D);
+        } else {
+            for (int k = 0; k < 3; ++k)                  // :125-127
+                if ((rc = advect(k + 1, V[k], V0[k]))) return rc;
+        }
         if ((rc = project())) return rc;                 // :130
         if (!S->elide_dead) {                            // :135 (its result is overwritten by :136)
             if ((rc = diffuse_T(0, FS_DENS, FS_BUFFER))) return rc;
@@ -860,6 +870,8 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         s->elide_dead = (v != "0");
     } else if (k == "dump_async") {
         s->dump_async = (v != "0");
+    } else if (k == "fuse_advect") {
+        s->fuse_advect = (v != "0");
     } else if (k == "overlap") {
         s->overlap = (v != "0");
     } else if (k == "debug_poison_gather") {

@@ -1122,6 +1122,75 @@ __global__ __launch_bounds__(256) void advect_kernel(GridDesc g, SlabCtx sc, int
     write_face_ghosts(g, sc, field, c, x, y, z, u, b);
 }
 
+// The three velocity advections of a step (simulation.cpp:125-127) in one pass.  advect(2)
+// and advect(3) read the already advected v_x / v_y only at their own cell (:380-382), so one
+// thread can chain them: trace v_x, then v_y with the new (stored) v_x, then v_z with the new
+// v_x and v_y.  Eight array streams instead of fifteen; results are bit-identical.
+template <class T>
+__device__ __forceinline__ T back_trace(const GridDesc& g, const T* __restrict__ src, int x, int y, int z, T ux, T uy,
+                                        T uz, T kx, T ky, T kz)
+{
+    const T one = (T)1, half = (T)0.5;
+    T px = clamp_ref<T>((T)x - kx * ux, half, (T)g.W + half);          // :384-390
+    T py = clamp_ref<T>((T)y - ky * uy, half, (T)g.H + half);
+    T pz = clamp_ref<T>((T)z - kz * uz, half, (T)g.D + half);
+    const int x0 = (int)floor(px), y0 = (int)floor(py), z0 = (int)floor(pz);
+    const T tx = px - (T)x0, ty = py - (T)y0, tz = pz - (T)z0;
+    const T* s = src + cell(g, x0, y0, z0);
+    const T a00 = s[0] * (one - tx) + s[1] * tx;                          // :412-415
+    const T a01 = s[g.sz] * (one - tx) + s[g.sz + 1] * tx;
+    const T a10 = s[g.sy] * (one - tx) + s[g.sy + 1] * tx;
+    const T a11 = s[g.sy + g.sz] * (one - tx) + s[g.sy + g.sz + 1] * tx;
+    const T b0 = a00 * (one - ty) + a10 * ty;                             // :417-418
+    const T b1 = a01 * (one - ty) + a11 * ty;
+    return b0 * (one - tz) + b1 * tz;                                     // :420
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void advect_velocity_kernel(GridDesc g, SlabCtx sc, T* __restrict__ vx,
+                                                               T* __restrict__ vy, T* __restrict__ vz,
+                                                               const T* __restrict__ px, const T* __restrict__ py,
+                                                               const T* __restrict__ pz,
+                                                               const uint8_t* __restrict__ flags, T kx, T ky, T kz)
+{
+    const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int z = 1 + blockIdx.z;
+    if (x > g.W || y > g.H) return;
+    const long c = cell(g, x, y, z);
+    const unsigned f = flags[c];
+    const bool near = (f & F_NEAR) != 0;
+    T nx = (T)0, ny = (T)0, nz = (T)0;                   // un-zeroed results (0 inside solids, :375-377)
+    T sx = (T)0, sy = (T)0;                              // what setBounds leaves in v_x, v_y
+    if (!(f & F_SOLID)) {
+        const T oy = vy[c], oz = vz[c];
+        nx = back_trace<T>(g, px, x, y, z, px[c], oy, oz, kx, ky, kz);
+        sx = near ? (T)0 : nx;
+        ny = back_trace<T>(g, py, x, y, z, sx, py[c], oz, kx, ky, kz);
+        sy = near ? (T)0 : ny;
+        nz = back_trace<T>(g, pz, x, y, z, sx, sy, pz[c], kx, ky, kz);
+    }
+    vx[c] = near ? (T)0 : nx;
+    vy[c] = near ? (T)0 : ny;
+    vz[c] = near ? (T)0 : nz;
+    write_face_ghosts(g, sc, vx, c, x, y, z, nx, 1);
+    write_face_ghosts(g, sc, vy, c, x, y, z, ny, 2);
+    write_face_ghosts(g, sc, vz, c, x, y, z, nz, 3);
+}
+
+template <class T>
+void launch_advect_velocity(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz, const T* px,
+                            const T* py, const T* pz, const uint8_t* flags, T kx, T ky, T kz)
+{
+    hipLaunchKernelGGL((advect_velocity_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, px, py, pz, flags,
+                       kx, ky, kz);
+}
+template void launch_advect_velocity<float>(hipStream_t, const GridDesc&, const SlabCtx&, float*, float*, float*,
+                                            const float*, const float*, const float*, const uint8_t*, float, float, float);
+template void launch_advect_velocity<double>(hipStream_t, const GridDesc&, const SlabCtx&, double*, double*, double*,
+                                             const double*, const double*, const double*, const uint8_t*, double, double,
+                                             double);
+
 template <class T>
 void launch_advect(hipStream_t st, const GridDesc& g, const SlabCtx& sc, int b, T* field, const T* prev, const T* vx,
                    const T* vy, const T* vz, const uint8_t* flags, T kx, T ky, T kz, long prev_zshift)
