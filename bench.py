@@ -256,6 +256,23 @@ def main():
         }
         s2.close()
 
+    if world == 1 and not args.no_extra and name == "c3":
+        # transparency: the reference's density diffusion is dead work (its result is overwritten by
+        # the following advect, simulation.cpp:135-136).  The headline above executes it; this is
+        # the same workload with it elided (identical fields, tests/test_gpu_parity.py).
+        s3 = F.Simulation(W, H, D, 3, acc=acc, quiet=1, dump_every=0, elide_dead_density_solve=1)
+        with tempfile.TemporaryDirectory() as tmp:
+            add_obstacles(F, s3, cfg, tmp)
+        s3.run_one()
+        s3.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            s3.run_one()
+        s3.sync()
+        out["extra_dead_density_solve_elided"] = {"cells_steps_per_sec": cells * 3 / (time.perf_counter() - t0),
+                                                  "note": "not the headline; 5*acc instead of 6*acc sweeps per step"}
+        s3.close()
+
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(acc, budget_s=args.cpu_budget)
     print(json.dumps(out))

@@ -1,0 +1,139 @@
+"""Edge cases of the C ABI on the GPU: degenerate parameters, obstacles edited between steps,
+aliasing-sensitive call orders, repeated runs."""
+import numpy as np
+import pytest
+
+from conftest import ball_mask, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fluid_simulation_amd as F
+    return F
+
+
+def pair(F, O, W, H, D, solver, **kw):
+    sim = F.Simulation(W, H, D, kw.get("iter", 1), solver=solver, quiet=1, **{k: v for k, v in kw.items() if k != "iter"})
+    ora = O.Oracle(W, H, D, solver=O.JACOBI if solver == "jacobi" else O.GS_LEX, threads=1, **kw)
+    return sim, ora
+
+
+def same_state(F, O, sim, ora, what):
+    for f in range(11):
+        assert bits_equal(sim.get(f), ora.get(f)), "%s: %s" % (what, F.FIELD_NAMES[f])
+
+
+@pytest.mark.parametrize("solver", ["jacobi", "gs_lex"])
+def test_zero_solver_iterations(F, oracle_mod, solver):
+    """acc = 0: no sweeps at all; the snapshots must still be real copies (advection reads them)."""
+    O = oracle_mod
+    sim, ora = pair(F, O, 14, 9, 7, solver, acc=0)
+    m = ball_mask(14, 9, 7, 5, 4, 3, 2.2)
+    sim.set_mask(m)
+    ora.set_mask(m)
+    for _ in range(3):
+        sim.run_one()
+        ora.run_one()
+    same_state(F, O, sim, ora, "acc=0 " + solver)
+
+
+def test_odd_and_single_iteration_counts(F, oracle_mod):
+    O = oracle_mod
+    for acc in (1, 2, 3, 7):
+        sim, ora = pair(F, O, 18, 11, 9, "jacobi", acc=acc)
+        for _ in range(2):
+            sim.run_one()
+            ora.run_one()
+        same_state(F, O, sim, ora, "acc=%d" % acc)
+
+
+def test_obstacles_edited_between_steps(F, oracle_mod):
+    """The reference never edits obs after loading, but nothing forbids it: flags must follow."""
+    O = oracle_mod
+    sim, ora = pair(F, O, 16, 12, 10, "jacobi", acc=4)
+    sim.run_one()
+    ora.run_one()
+    for s in (sim,):
+        s.addObstacle(6, 6, 5)
+        s.addObstacle(7, 6, 5)
+    ora.add_obstacle(6, 6, 5)
+    ora.add_obstacle(7, 6, 5)
+    sim.run_one()
+    ora.run_one()
+    m = ball_mask(16, 12, 10, 11, 5, 5, 2.0)
+    cur = ora.get(O.OBS) > 0.5
+    sim.set_mask(m | cur)
+    ora.set_mask(m | cur)
+    sim.run_one()
+    ora.run_one()
+    same_state(F, O, sim, ora, "edited obstacles")
+
+
+def test_mutators_between_steps_and_member_changes(F, oracle_mod):
+    O = oracle_mod
+    sim, ora = pair(F, O, 12, 10, 8, "jacobi", acc=5)
+    sim.run_one()
+    ora.run_one()
+    sim.addDensity(4, 4, 4, 0.3)
+    ora.add_density(4, 4, 4, 0.3)
+    sim.setVelocity(5, 5, 5, 2.0, -1.0, 0.25)
+    ora.set_velocity(5, 5, 5, 2.0, -1.0, 0.25)
+    sim.step()           # step() alone: no inlet density, buffer keeps the previous dens
+    ora.step_only()
+    same_state(F, O, sim, ora, "mutators + step()")
+    sim.speed = 12
+    sim.acc = 3
+    sim.dt = 0.02
+    o2 = O.Oracle(12, 10, 8, solver=O.JACOBI, threads=1, acc=3, speed=12, dt=0.02)
+    for f in range(11):
+        o2.set(f, ora.get(f))
+    sim.run_one()
+    o2.run_one()
+    same_state(F, O, sim, o2, "changed speed/acc/dt")
+
+
+def test_set_get_roundtrip_and_types(F):
+    sim = F.Simulation(9, 6, 5, 1, quiet=1)
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((7, 8, 11)).astype(np.float32)
+    sim.set(F.VY, a)
+    assert bits_equal(sim.get(F.VY), a)
+    assert np.array_equal(sim.get(F.VY, dtype=np.float64), a.astype(np.float64))
+    sim.set(F.DENS, a.astype(np.float64))
+    assert bits_equal(sim.get(F.DENS), a)
+    with pytest.raises(F.FluidsimError):
+        sim.set(F.VX, a[:-1])                 # wrong size
+
+
+def test_two_handles_are_independent(F, oracle_mod):
+    O = oracle_mod
+    s1, o1 = pair(F, O, 10, 8, 6, "jacobi", acc=4)
+    s2, o2 = pair(F, O, 20, 6, 9, "jacobi", acc=2)
+    for _ in range(2):
+        s1.run_one()
+        s2.run_one()
+        o1.run_one()
+        o2.run_one()
+    same_state(F, O, s1, o1, "handle 1")
+    same_state(F, O, s2, o2, "handle 2")
+
+
+def test_run_twice_truncates_dumps(F, tmp_path):
+    sim = F.Simulation(6, 5, 4, 2, acc=2, quiet=1, dump_dir=str(tmp_path))
+    sim.run()
+    sim.run()           # the reference's run() re-opens (truncates) its files
+    sim.close()
+    assert (tmp_path / "data.bin").stat().st_size == 2 * 8 * 7 * 6 * 4
+
+
+def test_fs_run_statistics_lines(F, capfd):
+    sim = F.Simulation(8, 6, 5, 100, acc=1, dump_every=0)
+    sim.run()
+    sim.close()
+    out = capfd.readouterr().out
+    assert "starting 3-D simulation: 8x6x5  steps = 100" in out
+    assert "step 100" in out and "density sum = " in out
+    for k in ("density  min", "density  max", "velocity x min", "velocity z max", "simulation finished"):
+        assert k in out
