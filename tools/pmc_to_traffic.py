@@ -14,7 +14,8 @@ import sys
 
 fetch_dir, write_dir, workload = sys.argv[1:4]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = ("jacobi_pair_kernel", "jacobi_sweep_kernel", "advect_kernel", "divergence_kernel", "gradient_kernel")
+KEYS = ("jacobi_pair_kernel", "jacobi_sweep_kernel", "advect_velocity_kernel", "advect_kernel", "divergence_march_kernel",
+        "gradient_march_kernel", "divergence_kernel", "gradient_kernel")
 
 
 def mean_by_kernel(d, counter):
