@@ -1162,6 +1162,7 @@ int fs_comm_init(fs_sim* s, int rank, int nranks, const void* id)
     if (s->eng) return fail(FS_EINVAL, "fs_comm_init must precede first use of the handle");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(FS_EINVAL, "bad rank %d of %d", rank, nranks);
     if (s->D % nranks) return fail(FS_EINVAL, "depth %d does not divide over %d slabs", s->D, nranks);
+    if (nranks > 1 && s->D / nranks < 2) return fail(FS_EINVAL, "a slab needs at least 2 planes (two-deep halos), got %d", s->D / nranks);
     if (nranks == 1) return FS_OK;
     hipSetDevice(s->device);
     if (s->comm.init(rank, nranks, id)) return fail(FS_ECOMM, "%s", s->comm.last_error());
