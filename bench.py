@@ -61,14 +61,10 @@ def cpu_baseline(acc, budget_s=12.0):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("FS_CPU_BASELINE_THREADS", "16"))))
-    try:
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
-    except OSError:
-        pass
     z, y, x = np.mgrid[0:D + 2, 0:H + 2, 0:W + 2]
     mask = ((x - 16) ** 2 + (y - 32) ** 2 + (z - 32) ** 2) <= 64
     if O.have_reference():
-        kind, sim = "reference", O.Reference(W, H, D, iter=1, acc=acc)
+        kind, sim = "reference", O.Reference(W, H, D, threads=cores, iter=1, acc=acc)
     else:
         kind, sim = "port", O.Oracle(W, H, D, solver=O.GS_LEX, threads=cores, iter=1, acc=acc)
     sim.set_mask(mask)

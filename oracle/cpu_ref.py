@@ -29,6 +29,31 @@ def build(force=False):
                               stdout=subprocess.DEVNULL)
 
 
+_gomp = None
+
+
+def _set_omp_threads(n):
+    """The oracle and the reference shim share one libgomp: its thread count is process-global, so
+    every call into either library sets the count it wants first."""
+    global _gomp
+    if _gomp is None:
+        try:
+            _gomp = C.CDLL("libgomp.so.1")
+        except OSError:
+            _gomp = False
+    if _gomp:
+        _gomp.omp_set_num_threads(C.c_int(int(n)))
+
+
+def default_threads(cap=8):
+    """Never the OpenMP default: a GPU box reports all 256 host cores but grants 16."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, cap))
+
+
 def _load(name):
     path = os.path.join(HERE, name)
     if not os.path.exists(path):
@@ -40,6 +65,7 @@ class _Sim:
     """Common shape of both back-ends: create / mutate / step / read back."""
     prefix = None
     dtype = np.float32
+    threads = 1
 
     def __init__(self, lib, w, h, d, iter=1, speed=30, dt=0.05, diff=2.0e-5, visc=1.5e-5, acc=15):
         self.lib = lib
@@ -54,6 +80,7 @@ class _Sim:
             raise MemoryError("oracle create failed")
 
     def _call(self, name, *args, restype=None):
+        _set_omp_threads(self.threads)
         fn = getattr(self.lib, self.prefix + name)
         fn.restype = restype
         return fn(self.h, *args)
@@ -124,15 +151,9 @@ class Oracle(_Sim):
         lib = _load("libcpu_ref64.so" if fp64 else "libcpu_ref.so")
         self.dtype = np.float64 if fp64 else np.float32
         super().__init__(lib, w, h, d, **kw)
+        # GS_LEX is only the reference's one-thread order at one thread; Jacobi is thread-independent
+        self.threads = threads if threads is not None else (1 if solver == GS_LEX else default_threads())
         self._call("set_solver", C.c_int(solver))
-        if threads is None:
-            # never the OpenMP default: a GPU box reports all 256 host cores but grants 16
-            try:
-                threads = len(os.sched_getaffinity(0))
-            except AttributeError:
-                threads = os.cpu_count() or 1
-            threads = max(1, min(threads, 8))
-        lib.cr_set_threads(C.c_int(threads))
 
     def load_stl(self, path, scale=0.8, rot=(0.0, 0.0, 0.0), translate=(0.0, 0.0, 0.0), seed=1):
         return self._call("load_stl", C.c_char_p(os.fsencode(path)), C.c_float(scale),
@@ -151,11 +172,13 @@ def have_reference():
 
 
 class Reference(_Sim):
-    """The compiled, unmodified reference (only meaningful at OMP_NUM_THREADS=1)."""
+    """The compiled, unmodified reference.  Deterministic only at one thread (the default here);
+    bench.py's cpu_baseline passes threads=<cores> to time it the way a user would run it."""
     prefix = "ref_"
 
-    def __init__(self, w, h, d, **kw):
+    def __init__(self, w, h, d, threads=1, **kw):
         super().__init__(C.CDLL(os.path.join(HERE, "_ref", "libref.so")), w, h, d, **kw)
+        self.threads = threads
 
     def load_stl(self, path, scale=0.8, rot=(0.0, 0.0, 0.0), translate=(0.0, 0.0, 0.0)):
         self._call("load_stl", C.c_char_p(os.fsencode(path)), C.c_float(scale),
