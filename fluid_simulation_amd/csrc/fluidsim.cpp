@@ -336,6 +336,8 @@ struct Engine : EngineBase {
         int src = cur;
         bool src_temp = false;
         const bool pairs = fs::pair_supported<T>(g, sc);
+        int pair_span = -1;
+        long pair_launches = 0;
         if (pairs && S->comm.active()) {
             // the pair kernel recomputes level 1 of the neighbours' boundary planes: it reads the
             // right-hand side there, so its first halo plane must be current
@@ -369,19 +371,36 @@ struct Engine : EngineBase {
                 }
                 HIP_TRY(hipEventRecord(ev_halo, comm_stream));
                 HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
-            } else {
+            } else if (S->comm.active()) {
                 {
                     ScopedSpan sp(S, two ? FAM_PAIR : FAM_SWEEP);
                     run(S->stream, 1, g.D);
                 }
                 int rc = halo(arr[dst]);
                 if (rc) return rc;
+            } else {
+                // single GPU: one event pair around the whole run of pair launches of this solve (an
+                // event pair per launch costs 2 % at 512^3 and 16 % at 256^3), one around a trailing
+                // single sweep; launches are counted so that time / launches is the mean launch time
+                if (two) {
+                    if (pair_span < 0) pair_span = S->span_begin(FAM_PAIR);
+                    ++pair_launches;
+                } else if (pair_span >= 0) {
+                    S->span_end(pair_span, pair_launches);
+                    pair_span = -1;
+                }
+                if (two) run(S->stream, 1, g.D);
+                else {
+                    ScopedSpan sp(S, FAM_SWEEP);
+                    run(S->stream, 1, g.D);
+                }
             }
             if (two) ++it;
             if (src_temp) held[src] = false;
             src = dst;
             src_temp = true;
         }
+        if (pair_span >= 0) S->span_end(pair_span, pair_launches);
         if (!src_temp) held[src] = true;
         *result = src;
         return FS_OK;
