@@ -173,8 +173,8 @@ struct Engine : EngineBase {
     uint8_t* kill = nullptr;            // one byte per four cells for the sweeps; byte (cell+3)/4
     bool flags_dirty = true;
     bool halos_dirty = false;           // a host-side mutation may have changed a slab boundary plane
-    void* dense = nullptr;              // device staging for pack/unpack: dense local slab, sizeof(double) per cell
-    void* pinned = nullptr;             // host staging for dumps
+    void* dense = nullptr;              // device staging of fs_get_field / fs_set_field (dense local slab), on demand
+    size_t dense_bytes = 0;
     T* gathered = nullptr;              // all-gathered advection source (z-slabs only), LEAD-shifted
     double* red = nullptr;              // stats scratch
     hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
@@ -184,6 +184,17 @@ struct Engine : EngineBase {
     explicit Engine(fs_sim* s) : S(s) {}
 
     long dense_cells() const { return (long)(g.W + 2) * (g.H + 2) * (g.D + 2); }
+
+    int need_dense(size_t bytes)
+    {
+        if (bytes <= dense_bytes) return FS_OK;
+        if (dense) HIP_TRY(hipFree(dense));
+        dense = nullptr;
+        dense_bytes = 0;
+        HIP_TRY(hipMalloc(&dense, bytes));
+        dense_bytes = bytes;
+        return FS_OK;
+    }
 
     int init()
     {
@@ -215,7 +226,6 @@ struct Engine : EngineBase {
         HIP_TRY(hipMalloc((void**)&kb, g.n / 4 + 16));
         HIP_TRY(hipMemsetAsync(kb, 0, g.n / 4 + 16, S->stream));
         kill = kb + (g.lead - fs::LEAD) / 4;
-        HIP_TRY(hipMalloc(&dense, dense_cells() * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&red, NRED * sizeof(double)));
         if (cm.active()) {
             int lo_pri = 0, hi_pri = 0;
@@ -235,7 +245,6 @@ struct Engine : EngineBase {
         if (kill) hipFree(kill - (g.lead - fs::LEAD) / 4);
         if (gathered) hipFree(gathered - fs::LEAD);   // global array with one ghost plane per side
         if (dense) hipFree(dense);
-        if (pinned) hipHostFree(pinned);
         if (red) hipFree(red);
         if (ev_edges) hipEventDestroy(ev_edges);
         if (ev_halo) hipEventDestroy(ev_halo);
@@ -614,6 +623,11 @@ struct Engine : EngineBase {
     {
         if ((long)n != dense_cells()) return fail(FS_EINVAL, "get_field: expected %ld elements, got %zu", dense_cells(), n);
         const T* f = arr[slot[which]];
+        if (elem != 1 && elem != 4 && elem != 8) return fail(FS_EINVAL, "elem_size must be 1, 4 or 8");
+        {
+            int rc = need_dense(n * (size_t)elem);
+            if (rc) return rc;
+        }
         if (elem == 4) fs::launch_pack<T, float>(S->stream, g, f, (float*)dense, 0, g.D + 1);
         else if (elem == 8) fs::launch_pack<T, double>(S->stream, g, f, (double*)dense, 0, g.D + 1);
         else if (elem == 1) fs::launch_pack<T, uint8_t>(S->stream, g, f, (uint8_t*)dense, 0, g.D + 1);
@@ -632,6 +646,10 @@ struct Engine : EngineBase {
             int id = acquire();
             if (id < 0) return fail(FS_ENOMEM, "array pool exhausted");
             adopt(which, id);
+        }
+        {
+            int rc = need_dense(n * (size_t)elem);
+            if (rc) return rc;
         }
         HIP_TRY(hipMemcpyAsync(dense, src, n * elem, hipMemcpyHostToDevice, S->stream));
         T* f = arr[slot[which]];
