@@ -164,6 +164,7 @@ def main():
     fams = ("sweep", "sweep_pair", "divergence", "gradient", "advect", "misc", "comm")
     fam = {k: sim.timing(k) for k in fams}
     local_cells = W * H * sim.local_depth
+    pair_shape = sim._geti("pair_shape")
     elem = 8 if args.precision == "fp64" else 4
     pair_ms, pair_n = fam["sweep_pair"]
     one_ms, one_n = fam["sweep"]
@@ -217,7 +218,7 @@ def main():
             "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": bytes_per_launch, "solver_iterations_per_launch": iters_per_launch,
-            "avg_launch_ms": avg_ms, "launches": k_n,
+            "avg_launch_ms": avg_ms, "launches": k_n, "workgroup_shape_id": pair_shape,
             "note": "achieved = 12 B x cells x iterations per launch / HIP-event launch time; above the "
                     "physical HBM rate when two iterations share one pass over memory (temporal blocking); "
                     "traffic = measured HBM bytes per launch (rocprofv3 PMC, profiles/)",

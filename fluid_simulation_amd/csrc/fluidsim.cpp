@@ -75,6 +75,7 @@ struct EngineBase {
     virtual int dump_frame() = 0;
     virtual int time_sweeps(int b, int field, int prev, float a, float c, int reps, double* ms) = 0;
     virtual int apply_solid_cells(const int* cells, long n) = 0;
+    virtual int tuned_shape() const = 0;
 };
 
 struct fs_sim {
@@ -177,6 +178,7 @@ struct Engine : EngineBase {
     size_t dense_bytes = 0;
     T* gathered = nullptr;              // all-gathered advection source (z-slabs only), LEAD-shifted
     double* red = nullptr;              // stats scratch
+    int pair_shape = -1;                // fastest pair-kernel workgroup shape for this grid (timed once)
     hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
     hipEvent_t ev_edges = nullptr, ev_halo = nullptr;
     static constexpr int NRED = 3 * 1024 + 3;
@@ -347,6 +349,10 @@ struct Engine : EngineBase {
         const bool pairs = fs::pair_supported<T>(g, sc);
         int pair_span = -1;
         long pair_launches = 0;
+        if (pairs && pair_shape < 0) {
+            int rc = choose_pair_shape(cur, rhs, b, a, inv_c);
+            if (rc) return rc;
+        }
         if (pairs && S->comm.active()) {
             // the pair kernel recomputes level 1 of the neighbours' boundary planes: it reads the
             // right-hand side there, so its first halo plane must be current
@@ -358,7 +364,7 @@ struct Engine : EngineBase {
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
             const bool two = pairs && it + 1 < sweeps;   // two sweeps per pass over memory
             auto run = [&](hipStream_t st, int zf, int zl) {
-                if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl);
+                if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape);
                 else fs::launch_jacobi<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl);
             };
             const int e = g.zh;                          // planes a neighbour needs from each boundary
@@ -412,6 +418,37 @@ struct Engine : EngineBase {
         if (pair_span >= 0) S->span_end(pair_span, pair_launches);
         if (!src_temp) held[src] = true;
         *result = src;
+        return FS_OK;
+    }
+
+    // Times the candidate workgroup shapes of the pair kernel on this grid (two launches each into a
+    // scratch array, the second one timed) and keeps the fastest.  Every shape computes the same
+    // bits, so this only ever changes speed.
+    int choose_pair_shape(int src, int rhs, int b, T a, T inv_c)
+    {
+        const int n = fs::pair_shape_count<T>(g);
+        pair_shape = 0;
+        if (n <= 1) return FS_OK;
+        int tmp = acquire(src, rhs);
+        if (tmp < 0) return fail(FS_ENOMEM, "array pool exhausted");
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        float best = 1e30f;
+        for (int shape = 0; shape < n; ++shape) {
+            float ms = 1e30f;
+            for (int rep = 0; rep < 2; ++rep) {
+                HIP_TRY(hipEventRecord(e0, S->stream));
+                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[rhs], arr[tmp], kill, b, a, inv_c, 1, g.D, shape);
+                HIP_TRY(hipEventRecord(e1, S->stream));
+                HIP_TRY(hipEventSynchronize(e1));
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            }
+            if (ms < best) { best = ms; pair_shape = shape; }
+        }
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        held[tmp] = false;
         return FS_OK;
     }
 
@@ -678,6 +715,8 @@ struct Engine : EngineBase {
         return FS_OK;
     }
 
+    int tuned_shape() const override { return pair_shape; }
+
     int apply_solid_cells(const int* cells, long n) override
     {
         // cells: device array of packed global cell ids x + y*(W+2) + z*(W+2)*(H+2)
@@ -780,7 +819,7 @@ struct Engine : EngineBase {
         const bool pairs = fs::pair_supported<T>(g, sc);
         for (int r = 0; r < reps; ++r) {
             if (pairs && r + 1 < reps) {
-                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D);
+                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D, pair_shape);
                 ++r;
             } else {
                 fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D);
@@ -950,6 +989,7 @@ int fs_get_int(fs_sim* s, const char* name, int* out)
     else if (n == "local_depth") *out = s->comm.active() ? s->comm.local_depth(s->D) : s->D;
     else if (n == "z_offset") *out = s->comm.active() ? s->comm.z_offset(s->D) : 0;
     else if (n == "last_advect_reach") *out = s->last_reach;
+    else if (n == "pair_shape") *out = s->eng ? s->eng->tuned_shape() : -1;
     else return fail(FS_EINVAL, "unknown int member '%s'", name);
     return FS_OK;
 }

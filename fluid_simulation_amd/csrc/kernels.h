@@ -63,7 +63,10 @@ template <class T>
 bool pair_supported(const GridDesc& g, const SlabCtx& sc);
 template <class T>
 void launch_jacobi_pair(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                        const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last);
+                        const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape);
+// number of workgroup shapes (0 .. count-1) worth timing for this grid; results do not depend on the shape
+template <class T>
+int pair_shape_count(const GridDesc& g);
 
 template <class T>
 void launch_gs_lex(hipStream_t st, const GridDesc& g, T* q, const T* rhs, const uint8_t* flags, int b, T a, T inv_c,

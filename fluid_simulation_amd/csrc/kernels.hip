@@ -548,14 +548,23 @@ template bool pair_supported<float>(const GridDesc&, const SlabCtx&);
 template bool pair_supported<double>(const GridDesc&, const SlabCtx&);
 
 template <>
+int pair_shape_count<float>(const GridDesc& g) { return (g.W <= 512) ? 3 : 1; }
+template <>
+int pair_shape_count<double>(const GridDesc&) { return 1; }
+
+template <>
 void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const float* src, const float* rhs,
-                               float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first, int z_last)
+                               float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first, int z_last,
+                               int shape)
 {
+    // shape: 0 = 12 waves (768 threads, <=168 VGPRs), 2 = 10 waves, 1 = 8 waves, 3 = 16 waves (spills;
+    // tuning tool only).  All shapes give identical results; the host driver times 0..count-1 once per
+    // grid and keeps the fastest (band count vs CU count decides, e.g. 10 waves at 512^3, 12 at 256^3).
     const int nxw = (g.W + 255) / 256;
-    const int shape = sweep_tune().pair_small;   // 0 = default (768 threads: 12 waves at <=168 VGPRs, one block per CU)
+    if (sweep_tune().pair_small > 0) shape = sweep_tune().pair_small;
 #define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last)
-    if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
-    else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
+    if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 2) FS_PAIR(1, 10); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
+    else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 2) FS_PAIR(2, 5); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
     else FS_PAIR(4, 3);
 #undef FS_PAIR
@@ -563,7 +572,7 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
 template <>
 void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const double* src,
                                 const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
-                                int z_first, int z_last)
+                                int z_first, int z_last, int /*shape*/)
 {
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
     if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last);
