@@ -46,6 +46,16 @@ def add_obstacles(F, sim, cfg, tmp):
     return added
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(acc, budget_s=12.0):
     """Reference CPU path timed on this box's host cores, on a bounded sample of the same kind
     of workload: a 64^3 tunnel with a ball obstacle at the workload's iteration count, stepped
@@ -68,19 +78,29 @@ def cpu_baseline(acc, budget_s=12.0):
     else:
         kind, sim = "port", O.Oracle(W, H, D, solver=O.GS_LEX, threads=cores, iter=1, acc=acc)
     sim.set_mask(mask)
-    sim.run_one()                       # warm caches / thread pool
-    n, t0 = 0, time.perf_counter()
-    while True:
-        sim.run_one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 200:
-            break
-    return {
+
+    def timed(budget):
+        sim.run_one()                   # warm caches / thread pool
+        n, t0 = 0, time.perf_counter()
+        while True:
+            sim.run_one()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget or n >= 200:
+                return n, el
+
+    n, el = timed(budget_s)
+    out = {
         "value": W * H * D * n / el, "unit": "cells*steps/s", "cores": cores, "kind": kind,
         "sample": "64x64x64 tunnel, ball obstacle r=8, acc=%d, %d steps in %.1f s, OpenMP %d threads, dumps off"
                   % (acc, n, el, cores),
+        "cpu_model": cpu_model(), "host_cpus_visible": os.cpu_count(),
     }
+    # the deterministic configuration of the reference, for orientation
+    sim.threads = 1
+    n1, el1 = timed(min(budget_s, 5.0))
+    out["value_1_thread"] = W * H * D * n1 / el1
+    return out
 
 
 def main():
@@ -269,6 +289,22 @@ def main():
         out["extra_dead_density_solve_elided"] = {"cells_steps_per_sec": cells * 3 / (time.perf_counter() - t0),
                                                   "note": "not the headline; 5*acc instead of 6*acc sweeps per step"}
         s3.close()
+
+    if world == 1 and not args.no_extra and name == "c3":
+        # also with the last frame dumped (fs_run, dump_every = -1), writer flushed
+        dump_root = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        with tempfile.TemporaryDirectory(dir=dump_root) as dtmp:
+            s4 = F.Simulation(W, H, D, 3, acc=acc, quiet=1, dump_every=-1, dump_dir=dtmp)
+            with tempfile.TemporaryDirectory() as tmp:
+                add_obstacles(F, s4, cfg, tmp)
+            s4.run_one()
+            s4.sync()
+            t0 = time.perf_counter()
+            s4.run()
+            s4.sync()
+            out["extra_last_frame_dump"] = {"cells_steps_per_sec": cells * 3 / (time.perf_counter() - t0),
+                                            "note": "3 steps through fs_run + one 2.7 GB frame written to " + (dump_root or "tmp")}
+            s4.close()
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(acc, budget_s=args.cpu_budget)
