@@ -102,6 +102,7 @@ JACOBI_CASES = [
     (600, 9, 7, 4, 1, "ball"),       # three 256-cell chunks per row (pair-kernel shape 3x4)
     (1000, 7, 6, 5, 1, "wall"),      # four chunks per row (shape 4x3), odd iteration count
     (40, 70, 30, 6, 1, "ball"),      # several row bands and z chunks in the pair kernel
+    (1100, 5, 4, 3, 1, "empty"),     # wider than the pair kernel supports: single-sweep kernel only
 ]
 
 
