@@ -33,6 +33,15 @@ def main():
     if stl:
         F.loadSTLIntoObstacles(stl, sim, 0.5, 0.0, 20.0, 0.0, 3.0, 0.0, 0.0)
     sim.run()
+    # host-side edits on and next to slab boundaries (every rank issues the same calls; a rank applies
+    # those that fall into its planes), then two more steps: the stale-halo bookkeeping must catch them
+    for zb in sorted({D // 2, D // 2 + 1, max(1, D // 4), min(D, 3 * D // 4 + 1)}):
+        sim.addDensity(5, 4, zb, 0.25)
+        sim.setVelocity(6, 5, zb, 1.5, -0.5, 2.0)
+        sim.addObstacle(9, 7, zb)
+    sim.set_option("dump_every", 0)
+    sim.run_one()
+    sim.run_one()
     out = {F.FIELD_NAMES[f]: sim.get(f) for f in (F.DENS, F.VX, F.VY, F.VZ, F.OBS, F.PRESSURE)}
     stats = np.array(sim.stats(F.DENS) + sim.stats(F.VX))
     reach = sim._geti("last_advect_reach")
