@@ -954,7 +954,7 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         s->debug_poison = (v != "0");
     } else if (k == "sweep_ry") {
         int r = atoi(value);
-        if (r != 2 && r != 4 && r != 8) return fail(FS_EINVAL, "sweep_ry: 2 | 4 | 8");
+        if (r != 2 && r != 4) return fail(FS_EINVAL, "sweep_ry: 2 | 4");
         fs::sweep_tune().ry = r;
     } else if (k == "sweep_zc") {
         fs::sweep_tune().zc_len = atoi(value);
@@ -972,8 +972,8 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         else return fail(FS_EINVAL, "project_kernels: march | cell");
     } else if (k == "pair_zc") {
         fs::sweep_tune().pair_zc = atoi(value);
-    } else if (k == "pair_small") {
-        fs::sweep_tune().pair_small = atoi(value);
+    } else if (k == "pair_shape") {
+        fs::sweep_tune().pair_shape = atoi(value);
     } else {
         return fail(FS_EINVAL, "unknown option '%s'", key);
     }

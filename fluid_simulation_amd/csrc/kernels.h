@@ -40,14 +40,14 @@ struct SlabCtx {
 // Tunables of the sweep launch (set through fs_set_option "sweep_ry" / "sweep_zc" /
 // "sweep_blocks"; "sweep_abl" selects timing-only ablation builds used by tools/tune_sweep.py).
 struct SweepTune {
-    int ry = 4;               // rows per wave patch: 2, 4 or 8
+    int ry = 2;               // rows per wave patch of the single-sweep kernel: 2 or 4
     int zc_len = 0;           // planes per z chunk; 0 = derive from target_blocks
     int target_blocks = 2048; // aim for about this many workgroups per launch
     int abl = 0;
     int fuse = 2;             // sweeps fused per pass over memory (1 = never fuse, 2 = pair kernel)
     int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic
     int project_cell = 0;     // 1 = per-cell divergence/gradient kernels instead of the z-marching ones
-    int pair_small = 0;       // pair-kernel workgroup shape: 0 = 12 waves (default), 1 = 8 waves, 3 = 16 waves
+    int pair_shape = 0;       // >0 forces a pair-kernel workgroup shape (1 = 8, 2 = 10, 3 = 16 waves); 0 = timed choice
 };
 SweepTune& sweep_tune();
 

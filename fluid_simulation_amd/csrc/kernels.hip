@@ -240,9 +240,8 @@ void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T
     const SweepTune& tune = sweep_tune();
 #define FS_GO(RY, ABL) launch_jacobi_v<T, RY, ABL>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last)
     if (tune.abl == 0) {
-        if (tune.ry == 2) FS_GO(2, 0);
-        else if (tune.ry == 8) FS_GO(8, 0);
-        else FS_GO(4, 0);
+        if (tune.ry == 4) FS_GO(4, 0);
+        else FS_GO(2, 0);
     } else {   // timing-only ablations (wrong results by design), RY = 4
         switch (tune.abl) {
             case 1: FS_GO(4, 1); break;
@@ -561,7 +560,7 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
     // tuning tool only).  All shapes give identical results; the host driver times 0..count-1 once per
     // grid and keeps the fastest (band count vs CU count decides, e.g. 10 waves at 512^3, 12 at 256^3).
     const int nxw = (g.W + 255) / 256;
-    if (sweep_tune().pair_small > 0) shape = sweep_tune().pair_small;
+    if (sweep_tune().pair_shape > 0) shape = sweep_tune().pair_shape;
 #define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 2) FS_PAIR(1, 10); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 2) FS_PAIR(2, 5); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }

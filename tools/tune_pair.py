@@ -27,4 +27,4 @@ def run(tag, **opts):
 run("single ry2 zc32", sweep_fuse=1, sweep_ry=2, sweep_zc=32)
 for small in (0, 2, 1):
     for zc in (0, 32, 43, 52, 64, 86, 128, 171, 256):
-        run("pair small=%d zc=%d" % (small, zc), sweep_fuse=2, pair_small=small, pair_zc=zc)
+        run("pair shape=%d zc=%d" % (small, zc), sweep_fuse=2, pair_shape=small, pair_zc=zc)

@@ -35,7 +35,7 @@ def run(tag, **opts):
 
 base = dict(sweep_ry=4, sweep_zc=0, sweep_blocks=2048, sweep_abl=0)
 run("default ry4 auto", **base)
-for ry in (2, 4, 8):
+for ry in (2, 4):
     for zc in (8, 16, 32, 64, 128):
         run("ry%d zc%d" % (ry, zc), **dict(base, sweep_ry=ry, sweep_zc=zc))
 for abl, name in ((1, "no flags"), (2, "no y-halo rows"), (4, "no rhs"), (8, "no store"), (3, "no flags+halo")):
