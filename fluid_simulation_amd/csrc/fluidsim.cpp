@@ -421,31 +421,33 @@ struct Engine : EngineBase {
         return FS_OK;
     }
 
-    // Times the candidate workgroup shapes of the pair kernel on this grid (two launches each into a
-    // scratch array, the second one timed) and keeps the fastest.  Every shape computes the same
+    // Times the candidate launch plans of the pair kernel on this grid -- workgroup shape x the three
+    // best z-chunk counts of the launcher's model -- two launches each into a scratch array, the second
+    // one timed, and keeps the fastest.  Every shape computes the same
     // bits, so this only ever changes speed.
     int choose_pair_shape(int src, int rhs, int b, T a, T inv_c)
     {
         const int n = fs::pair_shape_count<T>(g);
         pair_shape = 0;
-        if (n <= 1) return FS_OK;
         int tmp = acquire(src, rhs);
         if (tmp < 0) return fail(FS_ENOMEM, "array pool exhausted");
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         float best = 1e30f;
-        for (int shape = 0; shape < n; ++shape) {
-            float ms = 1e30f;
-            for (int rep = 0; rep < 2; ++rep) {
-                HIP_TRY(hipEventRecord(e0, S->stream));
-                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[rhs], arr[tmp], kill, b, a, inv_c, 1, g.D, shape);
-                HIP_TRY(hipEventRecord(e1, S->stream));
-                HIP_TRY(hipEventSynchronize(e1));
-                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        for (int shape = 0; shape < n; ++shape)
+            for (int alt = 0; alt < 3; ++alt) {          // candidate id = shape + 8 * (rank of the chunk count)
+                const int cand = shape + 8 * alt;
+                float ms = 1e30f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    HIP_TRY(hipEventRecord(e0, S->stream));
+                    fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[rhs], arr[tmp], kill, b, a, inv_c, 1, g.D, cand);
+                    HIP_TRY(hipEventRecord(e1, S->stream));
+                    HIP_TRY(hipEventSynchronize(e1));
+                    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                }
+                if (ms < best) { best = ms; pair_shape = cand; }
             }
-            if (ms < best) { best = ms; pair_shape = shape; }
-        }
         hipEventDestroy(e0);
         hipEventDestroy(e1);
         held[tmp] = false;

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 
 template <class T, int NXW, int NYW>
 static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                          const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last)
+                          const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt)
 {
     constexpr int BY = NYW * 2;
     const SweepTune& tune = sweep_tune();
@@ -519,16 +519,28 @@ static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, 
     const int nbands = (g.H + (BY - 2) - 1) / (BY - 2);
     // z chunks: each re-reads 4 level-0 planes and recomputes 2 level-1 planes, so keep them
     // long; pick the count that fills the CUs most evenly (one workgroup per CU)
-    int best_nzc = 1;
-    double best = -1.0;
+    // model: fraction of CU slots filled x useful fraction of a chunk's planes; `alt` picks the
+    // alt-th best chunk count by that model (the host driver times alt = 0, 1, 2 once per grid,
+    // because how the block count falls against the 256 CUs matters more than the model knows)
+    int cand_nzc[3] = {1, 1, 1};
+    double cand_eff[3] = {-1.0, -1.0, -1.0};
     const int slots = 256;
-    for (int nzc = 1; nzc <= 64 && planes / nzc >= 12; ++nzc) {
+    for (int nzc = 1; nzc <= 64 && (nzc == 1 || planes / nzc >= 12); ++nzc) {
         const long blocks = (long)nbands * nzc;
         const long rounds = (blocks + slots - 1) / slots;
         const int len = (planes + nzc - 1) / nzc;
         const double eff = (double)blocks / (double)(rounds * slots) * (double)len / (double)(len + 3);
-        if (eff > best + 1e-9) { best = eff; best_nzc = nzc; }
+        for (int k = 0; k < 3; ++k)
+            if (eff > cand_eff[k] + 1e-9) {
+                for (int j = 2; j > k; --j) { cand_eff[j] = cand_eff[j - 1]; cand_nzc[j] = cand_nzc[j - 1]; }
+                cand_eff[k] = eff;
+                cand_nzc[k] = nzc;
+                break;
+            }
     }
+    int pick = alt < 0 ? 0 : (alt > 2 ? 2 : alt);
+    while (pick > 0 && cand_eff[pick] < 0.0) --pick;
+    const int best_nzc = cand_nzc[pick];
     int zc_len = (planes + best_nzc - 1) / best_nzc;
     if (tune.pair_zc > 0) zc_len = tune.pair_zc < planes ? tune.pair_zc : planes;
     const int nzc = (planes + zc_len - 1) / zc_len;
@@ -560,8 +572,11 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
     // tuning tool only).  All shapes give identical results; the host driver times 0..count-1 once per
     // grid and keeps the fastest (band count vs CU count decides, e.g. 10 waves at 512^3, 12 at 256^3).
     const int nxw = (g.W + 255) / 256;
+    if (shape < 0) shape = 0;
+    const int alt = shape >> 3;                          // which of the three best chunk counts
+    shape &= 7;
     if (sweep_tune().pair_shape > 0) shape = sweep_tune().pair_shape;
-#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last)
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 2) FS_PAIR(1, 10); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 2) FS_PAIR(2, 5); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
@@ -571,13 +586,14 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
 template <>
 void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const double* src,
                                 const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
-                                int z_first, int z_last, int /*shape*/)
+                                int z_first, int z_last, int shape)
 {
+    const int alt = shape < 0 ? 0 : (shape >> 3);
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
-    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last);
-    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last);
-    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last);
-    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last);
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt);
+    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt);
 }
 
 // =====================================================================================
