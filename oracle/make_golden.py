@@ -190,6 +190,7 @@ def main():
     g2_passes()
     g3_voxelizer()
     g4_layout()
+    g5_stock_run()
     manifest = dict(
         compiler=subprocess.check_output(["g++", "--version"]).decode().splitlines()[0],
         flags="-std=c++20 -O2 -fopenmp -fPIC (reference Makefile:5 + -fPIC)",
@@ -198,6 +199,41 @@ def main():
     )
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1)
+
+
+def g5_stock_run():
+    """The reference program's own default run (simulation.cpp:429-451: 128x64x64, 100 steps,
+    acc 15, the hard-coded STL path missing => empty tunnel), at one thread, through the real
+    Simulation::run().  1.1 GB of dumps are reduced to SHA-256 digests: of each whole file and of
+    its first 40 frames (the CPU suite replays 40 steps, the GPU suite all 100)."""
+    import hashlib
+    W, H, D, steps, acc = 128, 64, 64, 100, 15
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from oracle import cpu_ref as O\n"
+        "r = O.Reference(%d, %d, %d, iter=%d, acc=%d)\n"
+        "r.load_stl('/media/raoul/Speed/Data/3D-Printing/Models/Cars/F1Car-basic.stl', 2.0, (90.0, 0.0, 0.0), (-16.0, 0.0, 0.0))\n"
+        "r.run()\n" % (ROOT, W, H, D, steps, acc))
+    frame = (W + 2) * (H + 2) * (D + 2) * 4
+    digests = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.mkdir(os.path.join(tmp, "data"))
+        subprocess.check_call([sys.executable, "-c", code], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for fn in ("data", "obs", "v_x", "v_y", "v_z"):
+            path = os.path.join(tmp, "data", fn + ".bin")
+            assert os.path.getsize(path) == steps * frame
+            h_all, h_40 = hashlib.sha256(), hashlib.sha256()
+            with open(path, "rb") as f:
+                for k in range(steps):
+                    buf = f.read(frame)
+                    h_all.update(buf)
+                    if k < 40:
+                        h_40.update(buf)
+            digests[fn] = {"sha256_100_frames": h_all.hexdigest(), "sha256_first_40_frames": h_40.hexdigest()}
+    meta = dict(kind="stock_run", W=W, H=H, D=D, steps=steps, acc=acc, speed=30, frame_bytes=frame, files=digests)
+    with open(os.path.join(OUT, "g5_stock_run_digests.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote g5_stock_run_digests.json")
 
 
 if __name__ == "__main__":

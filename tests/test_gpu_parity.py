@@ -407,3 +407,27 @@ def test_bench_line_contract(tmp_path):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 1000.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "64x64x64" in c["sample"]
+
+
+def test_stock_run_of_the_reference_program_byte_identical(tmp_path):
+    """`./simulation.out` with the reference's defaults (128x64x64, 100 steps, acc 15, STL path
+    missing), in the reference's own sweep order: all five dump files, 1.1 GB, must hash to what the
+    compiled reference wrote at one thread (tests/golden/g5_stock_run_digests.json)."""
+    import hashlib
+    import json
+    import subprocess
+    from conftest import ROOT
+    meta = json.load(open(os.path.join(GOLDEN, "g5_stock_run_digests.json")))
+    exe = os.path.join(ROOT, "simulation.out")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", ROOT, "simulation.out"])
+    (tmp_path / "data").mkdir()
+    out = subprocess.run([exe, "--solver", "gs_lex", "--quiet"], cwd=str(tmp_path), capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for fn, want in meta["files"].items():
+        h = hashlib.sha256()
+        with open(str(tmp_path / "data" / (fn + ".bin")), "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 24), b""):
+                h.update(chunk)
+        assert h.hexdigest() == want["sha256_100_frames"], fn

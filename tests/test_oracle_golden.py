@@ -134,3 +134,23 @@ def test_jacobi_differs_from_gs_but_is_thread_independent(oracle_mod):
     for _ in range(2):
         g.run_one()
     assert not bits_equal(res[0], g.get(O.VX))
+
+
+def test_stock_run_first_40_frames_digest(oracle_mod, tmp_path):
+    """The reference program's default run (simulation.cpp:429-451; empty tunnel because its
+    hard-coded STL path does not exist), reduced to SHA-256 digests by oracle/make_golden.py.
+    The oracle replays the first 40 of the 100 steps and must produce the same bytes on disk."""
+    import hashlib
+    import json
+    O = oracle_mod
+    meta = json.load(open(os.path.join(GOLDEN, "g5_stock_run_digests.json")))
+    W, H, D = meta["W"], meta["H"], meta["D"]
+    o = O.Oracle(W, H, D, solver=O.GS_LEX, threads=1, iter=40, acc=meta["acc"], speed=meta["speed"])
+    hashes = {fn: hashlib.sha256() for fn in meta["files"]}
+    for s in range(40):
+        o.run_one()
+        o.dump_frame(str(tmp_path), append=False)          # one frame at a time keeps the disk use small
+        for fn, h in hashes.items():
+            h.update((tmp_path / (fn + ".bin")).read_bytes())
+    for fn, h in hashes.items():
+        assert h.hexdigest() == meta["files"][fn]["sha256_first_40_frames"], fn
