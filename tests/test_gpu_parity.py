@@ -431,3 +431,55 @@ def test_stock_run_of_the_reference_program_byte_identical(tmp_path):
             for chunk in iter(lambda: f.read(1 << 24), b""):
                 h.update(chunk)
         assert h.hexdigest() == want["sha256_100_frames"], fn
+
+
+def test_one_step_at_256_cubed_matches_oracle_bit_exact(F, oracle_mod):
+    """BASELINE config 2's grid (256^3, ball obstacle), one whole step with a shortened solve
+    (acc = 4 keeps the CPU oracle at a few seconds): every field bit-identical."""
+    O = oracle_mod
+    W = H = D = 256
+    m = ball_mask(W, H, D, 80, 128, 128, 30)
+    sim = F.Simulation(W, H, D, 1, acc=4, quiet=1)
+    ora = O.Oracle(W, H, D, solver=O.JACOBI, acc=4)
+    sim.set_mask(m)
+    ora.set_mask(m)
+    sim.run_one()
+    ora.run_one()
+    for f in (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE, F.DIVERGENCE):
+        assert_same(sim.get(f), ora.get(f), "256^3 " + F.FIELD_NAMES[f])
+
+
+def test_wide_thin_slab_of_the_1024x512_grid_matches_oracle(F, oracle_mod):
+    """BASELINE config 4's plane size (1024 x 512) on a few planes: pair-kernel shape 4x3, four
+    256-cell chunks per row, 128 row bands."""
+    O = oracle_mod
+    W, H, D, acc = 1024, 512, 5, 4
+    m = ball_mask(W, H, D, 300, 256, 3, 60)
+    sim = F.Simulation(W, H, D, 1, acc=acc, quiet=1)
+    ora = O.Oracle(W, H, D, solver=O.JACOBI, acc=acc)
+    sim.set_mask(m)
+    ora.set_mask(m)
+    sim.run_one()
+    ora.run_one()
+    for f in (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE):
+        assert_same(sim.get(f), ora.get(f), "1024x512x5 " + F.FIELD_NAMES[f])
+
+
+def test_one_step_at_512_cubed_matches_oracle_bit_exact(F, oracle_mod):
+    """BASELINE config 3's grid (512^3, ball + plate-like slab of solids), one whole step with
+    acc = 2 (one pair launch per solve; the oracle needs ~6.5 GB and some seconds): bit-identical."""
+    O = oracle_mod
+    W = H = D = 512
+    m = ball_mask(W, H, D, 128, 256, 256, 60)
+    m[150:360, 180:330, 320:332] = True
+    sim = F.Simulation(W, H, D, 1, acc=2, quiet=1)
+    ora = O.Oracle(W, H, D, solver=O.JACOBI, acc=2)
+    sim.set_mask(m)
+    ora.set_mask(m)
+    del m
+    sim.run_one()
+    ora.run_one()
+    for f in (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE):
+        assert_same(sim.get(f), ora.get(f), "512^3 " + F.FIELD_NAMES[f])
+    sim.close()
+    ora.close()
