@@ -483,3 +483,23 @@ def test_one_step_at_512_cubed_matches_oracle_bit_exact(F, oracle_mod):
         assert_same(sim.get(f), ora.get(f), "512^3 " + F.FIELD_NAMES[f])
     sim.close()
     ora.close()
+
+
+def test_baseline_config2_first_step_exact(F, oracle_mod, tmp_path):
+    """BASELINE config 2 exactly as bench.py builds it (256^3, the synthetic sphere STL through
+    the loader, 40 solver iterations): obstacle mask and all fields after the first step must be
+    bit-identical with the oracle (its voxelizer and 240 sweeps take about a minute of CPU)."""
+    from fluid_simulation_amd import shapes
+    O = oracle_mod
+    W = H = D = 256
+    stl = shapes.write_binary_stl(str(tmp_path / "sphere.stl"), shapes.sphere_triangles(2.0, 48, 24))
+    sim = F.Simulation(W, H, D, 1, acc=40, quiet=1, voxel_seed=12345)
+    ora = O.Oracle(W, H, D, solver=O.JACOBI, acc=40)
+    n_gpu = F.loadSTLIntoObstacles(stl, sim, 0.3, 0.0, 0.0, 0.0, -W / 4.0, 0.0, 0.0)
+    n_cpu = ora.load_stl(stl, scale=0.3, translate=(-W / 4.0, 0.0, 0.0), seed=12345)
+    assert n_gpu == n_cpu and n_gpu > 100000
+    assert bits_equal(sim.get(F.OBS), ora.get(O.OBS))
+    sim.run_one()
+    ora.run_one()
+    for f in (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE):
+        assert_same(sim.get(f), ora.get(f), "config 2 " + F.FIELD_NAMES[f])
