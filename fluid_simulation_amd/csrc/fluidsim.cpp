@@ -363,22 +363,24 @@ struct Engine : EngineBase {
             int dst = acquire(src, rhs);
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
             const bool two = pairs && it + 1 < sweeps;   // two sweeps per pass over memory
-            auto run = [&](hipStream_t st, int zf, int zl) {
-                if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape);
-                else fs::launch_jacobi<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl);
+            auto run = [&](hipStream_t st, int zf, int zl, int second = -1) {
+                if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape, second);
+                else fs::launch_jacobi<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, second);
             };
             const int e = g.zh;                          // planes a neighbour needs from each boundary
             if (S->comm.active() && S->overlap && g.D >= 2 * e + 8) {
-                // Boundary planes first; their exchange then travels on the communication stream
-                // while the interior planes are computed.
+                // Boundary planes first (both regions in one launch); their exchange then travels on
+                // the high-priority communication stream while the interior planes are computed
+                // (SURVEY 8e).  Running the boundary launch concurrently with the interior one on a
+                // second stream was measured slower: the interior workgroups fill every CU.
                 const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
-                {
-                    ScopedSpan sp(S, two ? FAM_PAIR : FAM_SWEEP);
-                    if (!sc.lo_wall) run(S->stream, 1, e);
-                    if (!sc.hi_wall) run(S->stream, g.D - e + 1, g.D);
-                    HIP_TRY(hipEventRecord(ev_edges, S->stream));
-                    run(S->stream, in_lo, in_hi);
-                }
+                if (pair_span < 0) pair_span = S->span_begin(FAM_PAIR);   // one event pair per solve (exchanges included)
+                pair_launches += two ? 1 : 0;
+                if (!sc.lo_wall && !sc.hi_wall) run(S->stream, 1, e, g.D - e + 1);
+                else if (!sc.lo_wall) run(S->stream, 1, e);
+                else if (!sc.hi_wall) run(S->stream, g.D - e + 1, g.D);
+                HIP_TRY(hipEventRecord(ev_edges, S->stream));
+                run(S->stream, in_lo, in_hi);
                 HIP_TRY(hipStreamWaitEvent(comm_stream, ev_edges, 0));
                 {
                     int rc = S->comm.exchange_halo(comm_stream, arr[dst], g, sizeof(T), S->D, g.zh);
@@ -387,12 +389,11 @@ struct Engine : EngineBase {
                 HIP_TRY(hipEventRecord(ev_halo, comm_stream));
                 HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
             } else if (S->comm.active()) {
-                {
-                    ScopedSpan sp(S, two ? FAM_PAIR : FAM_SWEEP);
-                    run(S->stream, 1, g.D);
-                }
-                int rc = halo(arr[dst]);
-                if (rc) return rc;
+                if (pair_span < 0) pair_span = S->span_begin(FAM_PAIR);
+                pair_launches += two ? 1 : 0;
+                run(S->stream, 1, g.D);
+                int rc = S->comm.exchange_halo(S->stream, arr[dst], g, sizeof(T), S->D, g.zh);
+                if (rc) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
             } else {
                 // single GPU: one event pair around the whole run of pair launches of this solve (an
                 // event pair per launch costs 2 % at 512^3 and 16 % at 256^3), one around a trailing

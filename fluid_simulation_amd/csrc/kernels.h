@@ -54,7 +54,9 @@ SweepTune& sweep_tune();
 // NOTE: the sweep launchers take the KILL-byte array (launch_build_kill), not the flag bytes.
 template <class T>
 void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                   const uint8_t* kill, int b, T a, T inv_c, int z_first, int z_last);
+                   const uint8_t* kill, int b, T a, T inv_c, int z_first, int z_last, int second_first = -1);
+// second_first >= 0: ALSO compute the equally long range starting there, in the same launch (a
+// slab's two boundary regions)
 
 // Two sweeps in one pass (temporal blocking); same result as two launch_jacobi calls.
 // Needs W <= 1024; on a z-slab additionally two halo planes per side (g.zh == 2), current in
@@ -63,7 +65,8 @@ template <class T>
 bool pair_supported(const GridDesc& g, const SlabCtx& sc);
 template <class T>
 void launch_jacobi_pair(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                        const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape);
+                        const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
+                        int second_first = -1);
 // number of workgroup shapes (0 .. count-1) worth timing for this grid; results do not depend on the shape
 template <class T>
 int pair_shape_count(const GridDesc& g);

@@ -62,8 +62,8 @@ template <class T, int RY, int ABL>
 __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                             const T* __restrict__ rhs, T* __restrict__ dst,
                                                             const uint8_t* __restrict__ flags, int b, T a, T inv_c,
-                                                            int z_first, int z_last, int zc_len, int nxw, int nybg,
-                                                            int nblk)
+                                                            int z_first, int z_last, int zc_len, int z_stride, int nxw,
+                                                            int nybg, int nblk)
 {
     const int v = xcd_contiguous(blockIdx.x, nblk);
     const int xw = v % nxw;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
     if (y0 > H) return;                                  // wave-uniform
     const int x0 = 1 + xw * 256 + lane * 4;
     const bool lane_on = x0 <= W;
-    const int zbeg = z_first + zc * zc_len;
+    const int zbeg = z_first + zc * z_stride;            // z_stride == zc_len except for the two-range launch
     const int zend = min(z_last, zbeg + zc_len - 1);
     if (zbeg > zend) return;
 
@@ -211,16 +211,24 @@ SweepTune& sweep_tune()
 
 template <class T, int RY, int ABL>
 static void launch_jacobi_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                            const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last)
+                            const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int second_first)
 {
     const SweepTune& tune = sweep_tune();
     const int nxw = (g.W + 255) / 256;
     const int nyb = (g.H + RY - 1) / RY;
     const int nybg = (nyb + 3) / 4;
     const int planes = z_last - z_first + 1;
+    const long per_layer = (long)nxw * nybg;
+    if (second_first >= 0) {
+        // two equally long ranges (the slab's two boundary regions) as two chunks of one launch
+        const int last2 = second_first + planes - 1;
+        hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY, ABL>), dim3((unsigned)(per_layer * 2)), dim3(256), 0, st, g, sc, src,
+                           rhs, dst, flags, b, a, inv_c, z_first, last2, planes, second_first - z_first, nxw, nybg,
+                           (int)(per_layer * 2));
+        return;
+    }
     // enough z chunks for ~target_blocks blocks, but chunks of at least 8 planes (each chunk
     // re-reads 2 warm-up planes)
-    const long per_layer = (long)nxw * nybg;
     long want = (tune.target_blocks + per_layer - 1) / per_layer;
     if (want < 1) want = 1;
     int zc_len = (int)((planes + want - 1) / want);
@@ -229,16 +237,16 @@ static void launch_jacobi_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc
     const int nzc = (planes + zc_len - 1) / zc_len;
     const int nblk = (int)(per_layer * nzc);
     hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY, ABL>), dim3(nblk), dim3(256), 0, st, g, sc, src, rhs, dst, flags, b,
-                       a, inv_c, z_first, z_last, zc_len, nxw, nybg, nblk);
+                       a, inv_c, z_first, z_last, zc_len, zc_len, nxw, nybg, nblk);
 }
 
 template <class T>
 void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                   const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last)
+                   const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int second_first)
 {
     if (z_last < z_first) return;
     const SweepTune& tune = sweep_tune();
-#define FS_GO(RY, ABL) launch_jacobi_v<T, RY, ABL>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last)
+#define FS_GO(RY, ABL) launch_jacobi_v<T, RY, ABL>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, second_first)
     if (tune.abl == 0) {
         if (tune.ry == 4) FS_GO(4, 0);
         else FS_GO(2, 0);
@@ -255,9 +263,9 @@ void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T
 #undef FS_GO
 }
 template void launch_jacobi<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, const float*, float*,
-                                   const uint8_t*, int, float, float, int, int);
+                                   const uint8_t*, int, float, float, int, int, int);
 template void launch_jacobi<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, const double*, double*,
-                                    const uint8_t*, int, double, double, int, int);
+                                    const uint8_t*, int, double, double, int, int, int);
 
 // =====================================================================================
 // Two Jacobi sweeps per pass over memory (temporal blocking), bit-identical with two
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
                                                                      const T* __restrict__ rhs, T* __restrict__ dst,
                                                                      const uint8_t* __restrict__ flags, int b, T a,
                                                                      T inv_c, int z_first, int z_last, int zc_len,
-                                                                     int nbands, int nblk)
+                                                                     int z_stride, int nbands, int nblk)
 {
     constexpr int RY = 2, BY = NYW * RY, TW = NXW * 256 + 8;
     // ring of four level-1 plane tiles (plane z lives in slot z & 3); column index = x + 3
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
     const int ty0 = wy * RY, y0 = s + ty0;
     const int x0 = 1 + wx * 256 + lane * 4;
     const bool lane_on = x0 <= W;
-    const int zbeg = z_first + zc * zc_len, zend = min(z_last, zbeg + zc_len - 1);   // level-2 output planes
+    const int zbeg = z_first + zc * z_stride, zend = min(z_last, zbeg + zc_len - 1);  // level-2 output planes
     if (zbeg > zend) return;                             // block-uniform
     // level-1 planes: one beyond the output chunk on each side; beyond a physical wall there is
     // no such plane (its level-1 ghost is derived below), beyond a slab boundary it is the
@@ -510,13 +518,20 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 
 template <class T, int NXW, int NYW>
 static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                          const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt)
+                          const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt, int second_first)
 {
     constexpr int BY = NYW * 2;
     const SweepTune& tune = sweep_tune();
     const int planes = z_last - z_first + 1;
     if (planes <= 0) return;
     const int nbands = (g.H + (BY - 2) - 1) / (BY - 2);
+    if (second_first >= 0) {
+        // two equally long ranges (the slab's two boundary regions) as two chunks of one launch
+        hipLaunchKernelGGL((jacobi_pair_kernel<T, NXW, NYW>), dim3(nbands * 2), dim3(NXW * NYW * 64), 0, st, g, sc, src,
+                           rhs, dst, flags, b, a, inv_c, z_first, second_first + planes - 1, planes,
+                           second_first - z_first, nbands, nbands * 2);
+        return;
+    }
     // z chunks: each re-reads 4 level-0 planes and recomputes 2 level-1 planes, so keep them
     // long; pick the count that fills the CUs most evenly (one workgroup per CU)
     // model: fraction of CU slots filled x useful fraction of a chunk's planes; `alt` picks the
@@ -546,7 +561,7 @@ static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, 
     const int nzc = (planes + zc_len - 1) / zc_len;
     const int nblk = nbands * nzc;
     hipLaunchKernelGGL((jacobi_pair_kernel<T, NXW, NYW>), dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, sc, src, rhs,
-                       dst, flags, b, a, inv_c, z_first, z_last, zc_len, nbands, nblk);
+                       dst, flags, b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk);
 }
 
 template <class T>
@@ -566,7 +581,7 @@ int pair_shape_count<double>(const GridDesc&) { return 1; }
 template <>
 void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const float* src, const float* rhs,
                                float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first, int z_last,
-                               int shape)
+                               int shape, int second_first)
 {
     // shape: 0 = 12 waves (768 threads, <=168 VGPRs), 2 = 10 waves, 1 = 8 waves, 3 = 16 waves (spills;
     // tuning tool only).  All shapes give identical results; the host driver times 0..count-1 once per
@@ -576,7 +591,7 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
     const int alt = shape >> 3;                          // which of the three best chunk counts
     shape &= 7;
     if (sweep_tune().pair_shape > 0) shape = sweep_tune().pair_shape;
-#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt)
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 2) FS_PAIR(1, 10); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 2) FS_PAIR(2, 5); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
@@ -586,14 +601,14 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
 template <>
 void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const double* src,
                                 const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
-                                int z_first, int z_last, int shape)
+                                int z_first, int z_last, int shape, int second_first)
 {
     const int alt = shape < 0 ? 0 : (shape >> 3);
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
-    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt);
-    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt);
-    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt);
-    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt);
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first);
+    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first);
 }
 
 // =====================================================================================
