@@ -176,7 +176,8 @@ struct Engine : EngineBase {
     bool halos_dirty = false;           // a host-side mutation may have changed a slab boundary plane
     void* dense = nullptr;              // device staging of fs_get_field / fs_set_field (dense local slab), on demand
     size_t dense_bytes = 0;
-    T* gathered = nullptr;              // all-gathered advection source (z-slabs only), LEAD-shifted
+    T* gathered = nullptr;              // gathered advection source (z-slabs only), LEAD-shifted global array
+    T* gathered3[3] = {nullptr, nullptr, nullptr};   // the same for the three sources of the fused velocity advection
     double* red = nullptr;              // stats scratch
     int pair_shape = -1;                // fastest pair-kernel workgroup shape for this grid (timed once)
     hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
@@ -246,6 +247,8 @@ struct Engine : EngineBase {
         if (flags) hipFree(flags - g.lead);
         if (kill) hipFree(kill - (g.lead - fs::LEAD) / 4);
         if (gathered) hipFree(gathered - fs::LEAD);   // global array with one ghost plane per side
+        for (T* gp : gathered3)
+            if (gp) hipFree(gp - fs::LEAD);
         if (dense) hipFree(dense);
         if (red) hipFree(red);
         if (ev_edges) hipEventDestroy(ev_edges);
@@ -558,26 +561,10 @@ struct Engine : EngineBase {
             // carrying z velocity is `prev` for b == 3 and the current v_z otherwise
             // (simulation.cpp:382); its global max |.| gives the reach in planes, and only planes
             // within that reach of the slab are fetched from their owners.
-            if (!gathered) {
-                T* base = nullptr;
-                long n = g.sz * ((long)S->D + 2) + 8;
-                HIP_TRY(hipMalloc((void**)&base, n * sizeof(T)));
-                HIP_TRY(hipMemsetAsync(base, 0, n * sizeof(T), S->stream));
-                gathered = base + fs::LEAD;
-            }
             ScopedSpan sp(S, FAM_COMM);
-            double st3[3];
-            if ((rc = stats_of(arr[slot[b == 3 ? prev : FS_VZ]], st3))) return rc;
-            const double umax = std::fmax(std::fabs(st3[1]), std::fabs(st3[2]));
-            const double planes = std::ceil(std::fabs((double)kz) * umax) + 2.0;   // floor() and the +1 corner
-            const int reach = planes >= (double)S->D ? S->D : (int)planes;
-            S->last_reach = reach;
-            if (S->debug_poison) HIP_TRY(hipMemsetAsync(gathered - fs::LEAD, 0xFF, (g.sz * ((long)S->D + 2) + 8) * sizeof(T), S->stream));
-            if (reach >= S->D)
-                rc = S->comm.all_gather_planes(S->stream, src, gathered, g, S->D, sizeof(T));
-            else
-                rc = S->comm.gather_window(S->stream, src, gathered, g, S->D, sizeof(T), reach);
-            if (rc) return fail(FS_ECOMM, "gather of the advection source failed: %s", S->comm.last_error());
+            int reach = 0;
+            if ((rc = trace_reach({ b == 3 ? prev : FS_VZ }, &reach))) return rc;
+            if ((rc = gather_source(src, &gathered, reach))) return rc;
             src = gathered;
             zshift = (long)sc.zoff * g.sz;
         }
@@ -587,6 +574,68 @@ struct Engine : EngineBase {
                                  arr[slot[FS_VZ]], flags, kx, ky, kz, zshift);
         }
         return halo(arr[slot[field]]);
+    }
+
+    // Reach, in planes, of any back-trace whose carrying z velocity is one of `fields`: global
+    // max |u_z| over them (device reduction + all-reduce), times dt*D, plus the floor()/corner margin.
+    int trace_reach(std::initializer_list<int> fields, int* reach)
+    {
+        double umax = 0.0;
+        for (int f : fields) {
+            double st3[3];
+            int rc = stats_of(arr[slot[f]], st3);
+            if (rc) return rc;
+            umax = std::fmax(umax, std::fmax(std::fabs(st3[1]), std::fabs(st3[2])));
+        }
+        const double planes = std::ceil(std::fabs((double)S->dt * (double)S->D) * umax) + 2.0;
+        *reach = planes >= (double)S->D ? S->D : (int)planes;
+        S->last_reach = *reach;
+        return FS_OK;
+    }
+
+    int gather_source(const T* src, T** buf, int reach)
+    {
+        const long n = g.sz * ((long)S->D + 2) + 8;
+        if (!*buf) {
+            T* base = nullptr;
+            HIP_TRY(hipMalloc((void**)&base, n * sizeof(T)));
+            HIP_TRY(hipMemsetAsync(base, 0, n * sizeof(T), S->stream));
+            *buf = base + fs::LEAD;
+        }
+        if (S->debug_poison) HIP_TRY(hipMemsetAsync(*buf - fs::LEAD, 0xFF, n * sizeof(T), S->stream));
+        int rc = (reach >= S->D) ? S->comm.all_gather_planes(S->stream, src, *buf, g, S->D, sizeof(T))
+                                 : S->comm.gather_window(S->stream, src, *buf, g, S->D, sizeof(T), reach);
+        if (rc) return fail(FS_ECOMM, "gather of the advection source failed: %s", S->comm.last_error());
+        return FS_OK;
+    }
+
+    // advect(1,v_x,v_x_prev); advect(2,v_y,v_y_prev); advect(3,v_z,v_z_prev) in one kernel
+    int advect_velocity_fused()
+    {
+        int rc = ensure_flags();
+        if (rc) return rc;
+        const T kx = (T)S->dt * (T)S->W, ky = (T)S->dt * (T)S->H, kz = (T)S->dt * (T)S->D;   // :384-386
+        const T* p[3] = { arr[slot[FS_VX_PREV]], arr[slot[FS_VY_PREV]], arr[slot[FS_VZ_PREV]] };
+        long zshift = 0;
+        if (S->comm.active()) {
+            // the z velocity carrying the three traces is the current v_z (x, y) or v_z_prev (z)
+            ScopedSpan sp(S, FAM_COMM);
+            int reach = 0;
+            if ((rc = trace_reach({ FS_VZ, FS_VZ_PREV }, &reach))) return rc;
+            for (int k = 0; k < 3; ++k) {
+                if ((rc = gather_source(p[k], &gathered3[k], reach))) return rc;
+                p[k] = gathered3[k];
+            }
+            zshift = (long)sc.zoff * g.sz;
+        }
+        {
+            ScopedSpan sp(S, FAM_ADVECT);
+            fs::launch_advect_velocity<T>(S->stream, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]], p[0], p[1],
+                                          p[2], flags, kx, ky, kz, zshift);
+        }
+        for (int f : { FS_VX, FS_VY, FS_VZ })
+            if ((rc = halo(arr[slot[f]]))) return rc;
+        return FS_OK;
     }
 
     // ---- step (simulation.cpp:96-150) ---------------------------------------------------
@@ -617,13 +666,10 @@ struct Engine : EngineBase {
         for (int k = 0; k < 3; ++k)                      // :115-117
             if ((rc = diffuse_T(k + 1, V[k], V0[k]))) return rc;
         if ((rc = project())) return rc;                 // :120
-        if (!S->comm.active() && S->fuse_advect && slot[FS_VX] != slot[FS_VX_PREV] && slot[FS_VY] != slot[FS_VY_PREV] &&
+        if (S->fuse_advect && slot[FS_VX] != slot[FS_VX_PREV] && slot[FS_VY] != slot[FS_VY_PREV] &&
             slot[FS_VZ] != slot[FS_VZ_PREV]) {
             // :125-127 in one pass (the three traces only chain through the cell's own values)
-            ScopedSpan sp(S, FAM_ADVECT);
-            fs::launch_advect_velocity<T>(S->stream, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
-                                          arr[slot[FS_VX_PREV]], arr[slot[FS_VY_PREV]], arr[slot[FS_VZ_PREV]], flags,
-                                          (T)S->dt * (T)S->W, (T)S->dt * (T)S->H, (T)S->dt * (T)S->D);
+            if ((rc = advect_velocity_fused())) return rc;
         } else {
             for (int k = 0; k < 3; ++k)                  // :125-127
                 if ((rc = advect(k + 1, V[k], V0[k]))) return rc;

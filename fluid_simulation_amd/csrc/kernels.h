@@ -92,11 +92,11 @@ template <class T>
 void launch_advect(hipStream_t st, const GridDesc& g, const SlabCtx& sc, int b, T* field, const T* prev, const T* vx,
                    const T* vy, const T* vz, const uint8_t* flags, T kx, T ky, T kz, long prev_zshift);
 
-// advect(1,vx,px); advect(2,vy,py); advect(3,vz,pz) in one pass (single GPU: the sources are
-// whole local arrays)
+// advect(1,vx,px); advect(2,vy,py); advect(3,vz,pz) in one pass.  On a slab px/py/pz are the
+// gathered global arrays and zshift the element offset of this slab's plane 0 in them.
 template <class T>
 void launch_advect_velocity(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz, const T* px,
-                            const T* py, const T* pz, const uint8_t* flags, T kx, T ky, T kz);
+                            const T* py, const T* pz, const uint8_t* flags, T kx, T ky, T kz, long zshift);
 
 template <class T>
 void launch_build_flags(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* obs, uint8_t* flags);

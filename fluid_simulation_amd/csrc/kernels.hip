@@ -1166,16 +1166,18 @@ __global__ __launch_bounds__(256) void advect_kernel(GridDesc g, SlabCtx sc, int
 // thread can chain them: trace v_x, then v_y with the new (stored) v_x, then v_z with the new
 // v_x and v_y.  Eight array streams instead of fifteen; results are bit-identical.
 template <class T>
-__device__ __forceinline__ T back_trace(const GridDesc& g, const T* __restrict__ src, int x, int y, int z, T ux, T uy,
-                                        T uz, T kx, T ky, T kz)
+__device__ __forceinline__ T back_trace(const GridDesc& g, const SlabCtx& sc, const T* __restrict__ src, long zshift,
+                                        int x, int y, int z, T ux, T uy, T uz, T kx, T ky, T kz)
 {
+    // z is the local plane; the trace is clamped in global coordinates and `src + zshift` is indexed
+    // with local planes (zshift = zoff planes when src is the gathered global array of a slab)
     const T one = (T)1, half = (T)0.5;
     T px = clamp_ref<T>((T)x - kx * ux, half, (T)g.W + half);          // :384-390
     T py = clamp_ref<T>((T)y - ky * uy, half, (T)g.H + half);
-    T pz = clamp_ref<T>((T)z - kz * uz, half, (T)g.D + half);
+    T pz = clamp_ref<T>((T)(z + sc.zoff) - kz * uz, half, (T)sc.Dglobal + half);
     const int x0 = (int)floor(px), y0 = (int)floor(py), z0 = (int)floor(pz);
     const T tx = px - (T)x0, ty = py - (T)y0, tz = pz - (T)z0;
-    const T* s = src + cell(g, x0, y0, z0);
+    const T* s = src + zshift + cell(g, x0, y0, z0 - sc.zoff);
     const T a00 = s[0] * (one - tx) + s[1] * tx;                          // :412-415
     const T a01 = s[g.sz] * (one - tx) + s[g.sz + 1] * tx;
     const T a10 = s[g.sy] * (one - tx) + s[g.sy + 1] * tx;
@@ -1190,7 +1192,8 @@ __global__ __launch_bounds__(256) void advect_velocity_kernel(GridDesc g, SlabCt
                                                                T* __restrict__ vy, T* __restrict__ vz,
                                                                const T* __restrict__ px, const T* __restrict__ py,
                                                                const T* __restrict__ pz,
-                                                               const uint8_t* __restrict__ flags, T kx, T ky, T kz)
+                                                               const uint8_t* __restrict__ flags, T kx, T ky, T kz,
+                                                               long zshift)
 {
     const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -1203,11 +1206,11 @@ __global__ __launch_bounds__(256) void advect_velocity_kernel(GridDesc g, SlabCt
     T sx = (T)0, sy = (T)0;                              // what setBounds leaves in v_x, v_y
     if (!(f & F_SOLID)) {
         const T oy = vy[c], oz = vz[c];
-        nx = back_trace<T>(g, px, x, y, z, px[c], oy, oz, kx, ky, kz);
+        nx = back_trace<T>(g, sc, px, zshift, x, y, z, px[c + zshift], oy, oz, kx, ky, kz);
         sx = near ? (T)0 : nx;
-        ny = back_trace<T>(g, py, x, y, z, sx, py[c], oz, kx, ky, kz);
+        ny = back_trace<T>(g, sc, py, zshift, x, y, z, sx, py[c + zshift], oz, kx, ky, kz);
         sy = near ? (T)0 : ny;
-        nz = back_trace<T>(g, pz, x, y, z, sx, sy, pz[c], kx, ky, kz);
+        nz = back_trace<T>(g, sc, pz, zshift, x, y, z, sx, sy, pz[c + zshift], kx, ky, kz);
     }
     vx[c] = near ? (T)0 : nx;
     vy[c] = near ? (T)0 : ny;
@@ -1219,16 +1222,17 @@ __global__ __launch_bounds__(256) void advect_velocity_kernel(GridDesc g, SlabCt
 
 template <class T>
 void launch_advect_velocity(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz, const T* px,
-                            const T* py, const T* pz, const uint8_t* flags, T kx, T ky, T kz)
+                            const T* py, const T* pz, const uint8_t* flags, T kx, T ky, T kz, long zshift)
 {
     hipLaunchKernelGGL((advect_velocity_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, px, py, pz, flags,
-                       kx, ky, kz);
+                       kx, ky, kz, zshift);
 }
 template void launch_advect_velocity<float>(hipStream_t, const GridDesc&, const SlabCtx&, float*, float*, float*,
-                                            const float*, const float*, const float*, const uint8_t*, float, float, float);
+                                            const float*, const float*, const float*, const uint8_t*, float, float, float,
+                                            long);
 template void launch_advect_velocity<double>(hipStream_t, const GridDesc&, const SlabCtx&, double*, double*, double*,
                                              const double*, const double*, const double*, const uint8_t*, double, double,
-                                             double);
+                                             double, long);
 
 template <class T>
 void launch_advect(hipStream_t st, const GridDesc& g, const SlabCtx& sc, int b, T* field, const T* prev, const T* vx,
