@@ -137,3 +137,20 @@ def test_fs_run_statistics_lines(F, capfd):
     assert "step 100" in out and "density sum = " in out
     for k in ("density  min", "density  max", "velocity x min", "velocity z max", "simulation finished"):
         assert k in out
+
+
+def test_long_run_stays_bit_identical(F, oracle_mod):
+    """300 steps of a developed flow around a ball (64x32x32, acc 15): no drift between the GPU and
+    the oracle, checked every 100 steps."""
+    O = oracle_mod
+    W, H, D = 64, 32, 32
+    sim, ora = pair(F, O, W, H, D, "jacobi", acc=15)
+    m = ball_mask(W, H, D, 20, 16, 16, 6)
+    sim.set_mask(m)
+    ora.set_mask(m)
+    for s in range(300):
+        sim.run_one()
+        ora.run_one()
+        if (s + 1) % 100 == 0:
+            same_state(F, O, sim, ora, "step %d" % (s + 1))
+    assert float(sim.get(F.VX).max()) > 20.0
