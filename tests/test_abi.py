@@ -67,3 +67,31 @@ def test_version_string(libpath):
     lib = ctypes.CDLL(libpath)
     lib.fs_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.fs_version()
+
+
+def test_integration_md_cpp_shim_compiles(tmp_path):
+    """The drop-in `Simulation` shim shown in INTEGRATION.md must compile against include/fluidsim.h
+    (and, being the reference's main() verbatim on top of it, link against the library)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", text, flags=re.S)
+    assert blocks, "no C++ block in INTEGRATION.md"
+    src = tmp_path / "shim.cpp"
+    src.write_text(blocks[0] + """
+int main() {
+    Simulation sim(128, 64, 64, 100, 30);
+    loadSTLIntoObstacles("/nonexistent.stl", sim, 2.0f, 90.0f, 0.0f, 0.0f, -16.0f, 0.0f, 0.0f);
+    sim.addObstacle(1, 1, 1); sim.addDensity(1, 1, 1, 0.5f); sim.setVelocity(1, 1, 1, 1.f, 0.f, 0.f);
+    sim.run();
+    return sim.width + sim.acc;
+}
+""")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "shim.o")])
+
+
+def test_header_is_plain_c(tmp_path):
+    """The ABI header must be usable from C (no C++-only constructs outside the extern "C" guard)."""
+    src = tmp_path / "use.c"
+    src.write_text('#include "fluidsim.h"\nint main(void) { fs_sim* s = 0; (void)s; return FS_NFIELDS == 11 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c",
+                           str(src), "-o", str(tmp_path / "use.o")])
