@@ -16,7 +16,11 @@
 //   --stl PATH[,scale,rot_x,rot_y,rot_z,tx,ty,tz]   (repeatable; "none" = no obstacle)
 //   --dump-every N (0 = never, -1 = last frame only)  --dump-dir DIR
 //   --precision fp32|fp64   --solver jacobi|gs_lex   --seed N   --quiet
+//   --resume DIR   start from the last frame of DIR/{data,obs,v_x,v_y,v_z}.bin (a dumped frame is
+//                  a complete state: everything else is rebuilt every step)
+//   --json         append one machine-readable timing line to stdout
 // Each flag can also be given as an environment variable FS_GRID, FS_STEPS, ...
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -53,6 +57,29 @@ const char* opt(int argc, char** argv, int& i, const char* flag, const char* env
     return nullptr;
 }
 
+// last frame of one dump file -> field `which` (simulation.cpp:143-147 layout)
+int resume_field(fs_sim* sim, const std::string& dir, const char* name, int which)
+{
+    const size_t n = fs_padded_size(sim);
+    std::string path = dir + "/" + name;
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) { fprintf(stderr, "simulation.out: cannot open %s\n", path.c_str()); return 1; }
+    fseek(fp, 0, SEEK_END);
+    const long bytes = ftell(fp);
+    if (bytes <= 0 || (size_t)bytes % (n * sizeof(float)) != 0) {
+        fprintf(stderr, "simulation.out: %s is not a whole number of %zu-cell frames\n", path.c_str(), n);
+        fclose(fp);
+        return 1;
+    }
+    std::vector<float> frame(n);
+    fseek(fp, bytes - (long)(n * sizeof(float)), SEEK_SET);
+    const bool ok = fread(frame.data(), sizeof(float), n, fp) == n;
+    fclose(fp);
+    if (!ok) { fprintf(stderr, "simulation.out: short read from %s\n", path.c_str()); return 1; }
+    if (fs_set_field(sim, which, frame.data(), n, 4)) { fprintf(stderr, "simulation.out: %s\n", fs_last_error()); return 1; }
+    return 0;
+}
+
 int die(const char* what)
 {
     fprintf(stderr, "simulation.out: %s: %s\n", what, fs_last_error());
@@ -69,7 +96,8 @@ int main(int argc, char** argv)
     int iter = 100, speed = FS_DEFAULT_SPEED, acc = FS_DEFAULT_ACC;
     float dt = FS_DEFAULT_DT, diff = FS_DEFAULT_DIFF, visc = FS_DEFAULT_VISC;
     std::vector<Stl> stls;
-    bool stl_given = false;
+    bool stl_given = false, json = false;
+    std::string resume_dir;
     std::vector<std::pair<std::string, std::string>> options;
 
     auto apply = [&](const std::string& key, const char* val) -> bool {
@@ -85,10 +113,11 @@ int main(int argc, char** argv)
         if (key == "precision") { options.push_back({ "precision", val }); return true; }
         if (key == "solver") { options.push_back({ "solver", val }); return true; }
         if (key == "seed") { options.push_back({ "voxel_seed", val }); return true; }
+        if (key == "resume") { resume_dir = val; return true; }
         return false;
     };
     static const char* const keys[] = { "grid", "steps", "acc", "speed", "dt", "diff", "stl", "dump-every", "dump-dir",
-                                        "precision", "solver", "seed" };
+                                        "precision", "solver", "seed", "resume" };
     for (const char* k : keys) {
         std::string env = "FS_";
         for (const char* p = k; *p; ++p) env += (*p == '-') ? '_' : (char)toupper(*p);
@@ -99,6 +128,7 @@ int main(int argc, char** argv)
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--quiet") { options.push_back({ "quiet", "1" }); continue; }
+        if (a == "--json") { json = true; continue; }
         if (a.rfind("--", 0) != 0 || i + 1 >= argc || !apply(a.substr(2), argv[i + 1])) {
             fprintf(stderr, "simulation.out: unknown or malformed argument '%s' (see src/main.cpp)\n", argv[i]);
             return 2;
@@ -119,7 +149,19 @@ int main(int argc, char** argv)
         int rc = fs_load_stl(sim, s.path.c_str(), s.v[0], s.v[1], s.v[2], s.v[3], s.v[4], s.v[5], s.v[6], nullptr);
         if (rc != FS_OK && rc != FS_EIO) return die("fs_load_stl");   // unreadable STL: carry on with an empty tunnel
     }
+    if (!resume_dir.empty()) {
+        static const char* const names[5] = { "data.bin", "obs.bin", "v_x.bin", "v_y.bin", "v_z.bin" };
+        static const int which[5] = { FS_DENS, FS_OBS, FS_VX, FS_VY, FS_VZ };
+        for (int k = 0; k < 5; ++k)
+            if (resume_field(sim, resume_dir, names[k], which[k])) return 1;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
     if (fs_run(sim)) return die("fs_run");                              // simulation.cpp:448
+    if (fs_sync(sim)) return die("fs_sync");
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (json)
+        printf("{\"grid\": [%d, %d, %d], \"steps\": %d, \"acc\": %d, \"seconds\": %.6f, \"cells_steps_per_sec\": %.6g}\n",
+               width, height, depth, iter, acc, secs, (double)width * height * depth * iter / secs);
     fs_destroy(sim);
     return 0;
 }

@@ -503,3 +503,28 @@ def test_baseline_config2_first_step_exact(F, oracle_mod, tmp_path):
     ora.run_one()
     for f in (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE):
         assert_same(sim.get(f), ora.get(f), "config 2 " + F.FIELD_NAMES[f])
+
+
+def test_simulation_out_resume_and_json(tmp_path):
+    """A dumped frame is a complete state: 4 steps in one go and 2 steps + resume
+    from the dump + 2 steps end in byte-identical frames; --json appends a timing line."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "simulation.out")
+    base = [exe, "--grid", "24x16x12", "--acc", "6", "--quiet", "--stl", os.path.join(GOLDEN, "sphere_24x12.stl") + ",0.5,0,0,0,-4,0,0"]
+    for d in ("a", "b1", "b2"):
+        (tmp_path / d / "data").mkdir(parents=True)
+    subprocess.run(base + ["--steps", "4", "--json"], cwd=str(tmp_path / "a"), check=True, capture_output=True)
+    out = subprocess.run(base + ["--steps", "2", "--json"], cwd=str(tmp_path / "b1"), check=True, capture_output=True, text=True)
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["grid"] == [24, 16, 12] and line["steps"] == 2 and line["cells_steps_per_sec"] > 0
+    subprocess.run(base + ["--steps", "2", "--resume", str(tmp_path / "b1" / "data")], cwd=str(tmp_path / "b2"), check=True,
+                   capture_output=True)
+    frame = 26 * 18 * 14 * 4
+    for fn in ("data", "obs", "v_x", "v_y", "v_z"):
+        a = np.fromfile(str(tmp_path / "a" / "data" / (fn + ".bin")), dtype=np.uint8)
+        b = np.fromfile(str(tmp_path / "b2" / "data" / (fn + ".bin")), dtype=np.uint8)
+        assert a.size == 4 * frame and b.size == 2 * frame
+        assert np.array_equal(a[-frame:], b[-frame:]), fn
+        assert np.array_equal(a[2 * frame:3 * frame], b[:frame]), fn
