@@ -154,3 +154,26 @@ def test_long_run_stays_bit_identical(F, oracle_mod):
         if (s + 1) % 100 == 0:
             same_state(F, O, sim, ora, "step %d" % (s + 1))
     assert float(sim.get(F.VX).max()) > 20.0
+
+
+def test_create_destroy_does_not_leak_device_memory(F, tmp_path):
+    """Handles own everything they allocate (arrays, flags, staging, writer buffers, events)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    free0, total = ctypes.c_size_t(), ctypes.c_size_t()
+
+    def cycle(n):
+        for _ in range(n):
+            sim = F.Simulation(96, 64, 48, 2, acc=3, quiet=1, dump_dir=str(tmp_path))
+            sim.addObstacle(10, 10, 10)
+            sim.run()                      # steps + frame writer + statistics
+            sim.get(F.VX)
+            sim.close()
+
+    cycle(3)                               # warm up allocator pools / code objects
+    assert hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(total)) == 0
+    cycle(25)
+    free1 = ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(total)) == 0
+    leaked = int(free0.value) - int(free1.value)
+    assert leaked < 64 << 20, "device memory shrank by %d MB over 25 create/run/destroy cycles" % (leaked >> 20)
