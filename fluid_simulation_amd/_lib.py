@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfluidsim.so")
+# FLUIDSIM_LIB: development override (e.g. a host-sanitizer build of the same sources)
+LIB_PATH = os.environ.get("FLUIDSIM_LIB") or os.path.join(_HERE, "libfluidsim.so")
 
 OK, EINVAL, EIO, EHIP, ECOMM, ENOMEM = 0, -1, -2, -3, -4, -5
 DENS, VX, VY, VZ, OBS, PRESSURE, DIVERGENCE, VX_PREV, VY_PREV, VZ_PREV, BUFFER = range(11)
