@@ -22,8 +22,9 @@ def main():
     idfile, outdir = sys.argv[3], sys.argv[4]
     W, H, D, acc, steps = (int(v) for v in sys.argv[5:10])
     stl = sys.argv[10] if len(sys.argv) > 10 else ""
+    precision = sys.argv[11] if len(sys.argv) > 11 else "fp32"
     sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_dir=os.path.join(outdir, "data"), dump_every=1,
-                       voxel_seed=77, debug_poison_gather=1)
+                       voxel_seed=77, debug_poison_gather=1, precision=precision)
     if nranks > 1:
         sim.comm_init(rank, nranks, open(idfile, "rb").read())
     Dl, zoff = sim.local_depth, sim.z_offset

@@ -39,6 +39,21 @@ def test_zero_solver_iterations(F, oracle_mod, solver):
     same_state(F, O, sim, ora, "acc=0 " + solver)
 
 
+def test_fp64_reference_order_mode(F, oracle_mod):
+    """solver=gs_lex with fp64 fields against the fp64 oracle in GS_LEX mode."""
+    O = oracle_mod
+    W, H, D = 14, 10, 9
+    sim = F.Simulation(W, H, D, 1, acc=4, solver="gs_lex", precision="fp64", quiet=1)
+    ora = O.Oracle(W, H, D, solver=O.GS_LEX, fp64=True, threads=1, acc=4)
+    m = ball_mask(W, H, D, 5, 5, 4, 2.0)
+    sim.set_mask(m)
+    ora.set_mask(m)
+    for _ in range(2):
+        sim.run_one()
+        ora.run_one()
+    same_state(F, O, sim, ora, "fp64 gs_lex")
+
+
 def test_odd_and_single_iteration_counts(F, oracle_mod):
     O = oracle_mod
     for acc in (1, 2, 3, 7):

@@ -64,6 +64,24 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D):
         assert np.array_equal(a, b), fn
 
 
+@pytest.mark.parametrize("W,H,D,nranks,precision", [(300, 9, 24, 2, "fp32"), (20, 12, 16, 2, "fp64"), (520, 7, 36, 3, "fp32")])
+def test_slabs_wide_rows_and_fp64(tmp_path, W, H, D, nranks, precision):
+    """More than one 256-cell chunk per row (pair-kernel shapes 2xN / 3x4 on a slab) and fp64 fields."""
+    args = [W, H, D, 4, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision]
+    ref_dir = run_ranks(str(tmp_path), 1, args)
+    par_dir = run_ranks(str(tmp_path), nranks, args)
+    ref = np.load(os.path.join(ref_dir, "rank0.npz"))
+    Dl = D // nranks
+    u = np.uint64 if precision == "fp64" else np.uint32
+    for r in range(nranks):
+        z = np.load(os.path.join(par_dir, "rank%d.npz" % r))
+        zoff = int(z["zoff"])
+        for k in ("dens", "v_x", "v_y", "v_z", "obs"):
+            got, want = z[k], ref[k][zoff:zoff + Dl + 2]
+            assert got.dtype == want.dtype
+            assert np.array_equal(got.view(u), want.view(u)), (r, k)
+
+
 def test_depth_must_divide(tmp_path):
     import fluid_simulation_amd as F
     sim = F.Simulation(8, 8, 9, 1, quiet=1)
