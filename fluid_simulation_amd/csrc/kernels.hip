@@ -678,10 +678,49 @@ __global__ __launch_bounds__(1024) void gs_lex_kernel(GridDesc g, T* q, const T*
 }
 
 template <class T>
+void launch_set_bounds(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* q, const uint8_t* flags, int b);
+
+// Larger grids: the same order, tile by tile.  Cubic tiles of TS^3 cells are themselves swept in
+// hyperplane order I+J+L = k, one launch per k (tiles on one tile-hyperplane only touch tiles on
+// k-1, already done, and k+1, not yet started); inside a tile one workgroup walks the cell
+// hyperplanes with a barrier in between, as gs_lex_kernel does for the whole grid.
+template <class T, int TS>
+__global__ __launch_bounds__(TS* TS) void gs_tile_kernel(GridDesc g, T* q, const T* __restrict__ rhs, T a, T inv_c, int k,
+                                                          int nL)
+{
+    const int I = blockIdx.x, J = blockIdx.y, L = k - I - J;
+    if (L < 0 || L >= nL) return;                        // block-uniform
+    const int ly = threadIdx.x % TS, lz = threadIdx.x / TS;
+    const int y = 1 + J * TS + ly, z = 1 + L * TS + lz;
+    const bool yz_on = (y <= g.H) && (z <= g.D);
+    for (int s = 0; s < 3 * TS - 2; ++s) {
+        const int lx = s - ly - lz;
+        const int x = 1 + I * TS + lx;
+        if (yz_on && lx >= 0 && lx < TS && x <= g.W) {
+            const long c = cell(g, x, y, z);
+            T nb = q[c + 1] + q[c - 1] + q[c + g.sy] + q[c - g.sy] + q[c + g.sz] + q[c - g.sz];
+            q[c] = (rhs[c] + a * nb) * inv_c;
+        }
+        __syncthreads();
+    }
+}
+
+template <class T>
 void launch_gs_lex(hipStream_t st, const GridDesc& g, T* q, const T* rhs, const uint8_t* flags, int b, T a, T inv_c,
                    int sweeps)
 {
-    hipLaunchKernelGGL((gs_lex_kernel<T>), dim3(1), dim3(1024), 0, st, g, q, rhs, flags, b, a, inv_c, sweeps);
+    if ((long)g.W * g.H * g.D <= 32768) {                // small: one workgroup does the whole solve in one launch
+        hipLaunchKernelGGL((gs_lex_kernel<T>), dim3(1), dim3(1024), 0, st, g, q, rhs, flags, b, a, inv_c, sweeps);
+        return;
+    }
+    constexpr int TS = 16;
+    const int nI = (g.W + TS - 1) / TS, nJ = (g.H + TS - 1) / TS, nL = (g.D + TS - 1) / TS;
+    SlabCtx whole = { 0, g.D, 1, 1 };                    // gs_lex is single-GPU only
+    for (int it = 0; it < sweeps; ++it) {
+        for (int k = 0; k <= nI + nJ + nL - 3; ++k)
+            hipLaunchKernelGGL((gs_tile_kernel<T, TS>), dim3(nI, nJ), dim3(TS * TS), 0, st, g, q, rhs, a, inv_c, k, nL);
+        launch_set_bounds<T>(st, g, whole, q, flags, b);
+    }
 }
 template void launch_gs_lex<float>(hipStream_t, const GridDesc&, float*, const float*, const uint8_t*, int, float, float,
                                    int);

@@ -54,6 +54,25 @@ def test_fp64_reference_order_mode(F, oracle_mod):
     same_state(F, O, sim, ora, "fp64 gs_lex")
 
 
+@pytest.mark.parametrize("shape,fp64", [((50, 37, 41), False), ((70, 33, 17), True), ((33, 32, 33), False)])
+def test_tiled_reference_order_sweep_on_ragged_grids(F, oracle_mod, shape, fp64):
+    """Above 32768 cells solver=gs_lex sweeps 16^3 tiles in tile-hyperplane order, one launch per
+    tile hyperplane; the result must still be the reference's lexicographic in-place sweep, also
+    when the grid is not a multiple of the tile edge."""
+    O = oracle_mod
+    W, H, D = shape
+    kw = dict(precision="fp64") if fp64 else {}
+    sim = F.Simulation(W, H, D, 1, acc=3, solver="gs_lex", quiet=1, **kw)
+    ora = O.Oracle(W, H, D, solver=O.GS_LEX, fp64=fp64, threads=1, acc=3)
+    m = ball_mask(W, H, D, W // 3, H // 2, D // 2, min(H, D) / 4.0)
+    sim.set_mask(m)
+    ora.set_mask(m)
+    for _ in range(2):
+        sim.run_one()
+        ora.run_one()
+    same_state(F, O, sim, ora, "tiled gs_lex %s" % (shape,))
+
+
 def test_odd_and_single_iteration_counts(F, oracle_mod):
     O = oracle_mod
     for acc in (1, 2, 3, 7):
