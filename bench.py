@@ -103,6 +103,46 @@ def cpu_baseline(acc, budget_s=12.0):
     return out
 
 
+def slab_parity_check(F, fsdist, dist, rank, world, transport, ctl_device):
+    """N>1 only, before the timed run: every rank runs a small tunnel twice -- whole on its own
+    GPU, and as its z-slab of a world-wide run over the real transport (RCCL) -- and compares
+    its planes of every field bit for bit.  This is the multi-rank RCCL parity test that a
+    one-GPU box cannot run (tests/test_gpu_slabs.py does the same over shared memory)."""
+    import numpy as np
+    W, H, acc, steps = 96, 40, 7, 3
+    D = 16 * world                                       # 16 planes per rank: deep enough for the boundary-first overlapped exchange
+    z, y, x = np.mgrid[0:D + 2, 0:H + 2, 0:W + 2]
+    mask = ((x - W / 3.0) ** 2 + (y - H / 2.0) ** 2 + (z - (D / 2.0 + 1.5)) ** 2) <= (min(H, D) / 3.0) ** 2
+    mask[0] = mask[-1] = False
+    mask[:, 0] = mask[:, -1] = False
+    mask[:, :, 0] = mask[:, :, -1] = False
+    whole = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0)
+    whole.set_mask(mask)
+    slab = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0)
+    uid = fsdist.share_unique_id(dist, lambda: F.comm_unique_id(transport), rank, device=ctl_device)
+    slab.comm_init(rank, world, uid)
+    dl, zoff = slab.local_depth, slab.z_offset
+    slab.set_mask(mask[zoff:zoff + dl + 2])
+    for _ in range(steps):
+        whole.run_one()
+        slab.run_one()
+    bad = []
+    for f in (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE, F.DIVERGENCE):
+        a = whole.get(f)[zoff + 1:zoff + dl + 1]
+        b = slab.get(f)[1:dl + 1]
+        if a.tobytes() != b.tobytes():
+            bad.append(F.FIELD_NAMES[f])
+    ss, ws = slab.stats(F.VX), whole.stats(F.VX)         # (sum, min, max) over the global grid on every rank
+    stats_ok = ss[1:] == ws[1:] and abs(ss[0] - ws[0]) <= 1e-9 * max(1.0, abs(ws[0]))
+    slab.close()
+    whole.close()
+    flag = fsdist.max_over_ranks(dist, 1.0 if (bad or not stats_ok) else 0.0, device=ctl_device)
+    if bad or not stats_ok:
+        sys.stderr.write("rank %d: z-slab run differs from the single-GPU run in %s (stats ok: %s)\n" % (rank, bad, stats_ok))
+    return {"ok": flag == 0.0, "grid": [W, H, D], "steps": steps, "acc": acc,
+            "what": "every rank: its planes of dens/v/p/div of a %d-rank slab run vs the same run whole on its own GPU, bit-exact" % world}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,9 +196,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    sim = F.Simulation(W, H, D, args.steps, acc=acc, precision=args.precision, quiet=1, dump_every=0, profile=1)
+    slab_parity = None
     if world > 1:
         from fluid_simulation_amd import dist as fsdist
+        slab_parity = slab_parity_check(F, fsdist, dist, rank, world, args.transport, ctl_device)
+
+    sim = F.Simulation(W, H, D, args.steps, acc=acc, precision=args.precision, quiet=1, dump_every=0, profile=1)
+    if world > 1:
         uid = fsdist.share_unique_id(dist, lambda: F.comm_unique_id(args.transport), rank, device=ctl_device)
         sim.comm_init(rank, world, uid)
     with tempfile.TemporaryDirectory() as tmp:
@@ -244,6 +288,7 @@ def main():
                     "traffic = measured HBM bytes per launch (rocprofv3 PMC, profiles/)",
         },
         "kernel_ms": {k: {"total_ms": v[0], "launches": v[1]} for k, v in fam.items()},
+        "slab_parity": slab_parity,
         "step_bytes_per_cell_algorithmic": 208 + 72 * acc,
         "step_roofline_frac": (208 + 72 * acc) * (elem // 4) * cells * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
     }
