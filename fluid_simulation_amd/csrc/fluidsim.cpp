@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -44,8 +45,8 @@ int fail(int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail(FS_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-enum Family { FAM_SWEEP = 0, FAM_PAIR, FAM_DIV, FAM_GRAD, FAM_ADVECT, FAM_BOUNDS, FAM_MISC, FAM_COMM, FAM_COUNT };
-const char* const kFamilyNames[FAM_COUNT] = { "sweep", "sweep_pair", "divergence", "gradient", "advect", "bounds", "misc", "comm" };
+enum Family { FAM_SWEEP = 0, FAM_PAIR, FAM_TRIPLE, FAM_DIV, FAM_GRAD, FAM_ADVECT, FAM_BOUNDS, FAM_MISC, FAM_COMM, FAM_COUNT };
+const char* const kFamilyNames[FAM_COUNT] = { "sweep", "sweep_pair", "sweep_triple", "divergence", "gradient", "advect", "bounds", "misc", "comm" };
 
 constexpr int NPOOL = FS_NFIELDS + 3;   // named fields + ping-pong scratch
 
@@ -76,6 +77,7 @@ struct EngineBase {
     virtual int time_sweeps(int b, int field, int prev, float a, float c, int reps, double* ms) = 0;
     virtual int apply_solid_cells(const int* cells, long n) = 0;
     virtual int tuned_shape() const = 0;
+    virtual int tuned_triple() const = 0;
 };
 
 struct fs_sim {
@@ -180,6 +182,8 @@ struct Engine : EngineBase {
     T* gathered3[3] = {nullptr, nullptr, nullptr};   // the same for the three sources of the fused velocity advection
     double* red = nullptr;              // stats scratch
     int pair_shape = -1;                // fastest pair-kernel workgroup shape for this grid (timed once)
+    int tuned_fuse = -1;                // value of the sweep_fuse option the two choices below were timed under
+    int triple_alt = -1;                // >= 0: three sweeps per pass beat the pair kernel on this grid (launch plan id)
     hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
     hipEvent_t ev_edges = nullptr, ev_halo = nullptr;
     static constexpr int NRED = 3 * 1024 + 3;
@@ -350,9 +354,10 @@ struct Engine : EngineBase {
         int src = cur;
         bool src_temp = false;
         const bool pairs = fs::pair_supported<T>(g, sc);
-        int pair_span = -1;
+        int pair_span = -1, span_fam = FAM_PAIR;
         long pair_launches = 0;
-        if (pairs && pair_shape < 0) {
+        if (pairs && (pair_shape < 0 || tuned_fuse != fs::sweep_tune().fuse)) {
+            tuned_fuse = fs::sweep_tune().fuse;
             int rc = choose_pair_shape(cur, rhs, b, a, inv_c);
             if (rc) return rc;
         }
@@ -365,9 +370,11 @@ struct Engine : EngineBase {
         for (int it = 0; it < sweeps; ++it) {
             int dst = acquire(src, rhs);
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
-            const bool two = pairs && it + 1 < sweeps;   // two sweeps per pass over memory
+            const bool three = pairs && triple_alt >= 0 && it + 2 < sweeps;   // three sweeps per pass over memory
+            const bool two = pairs && !three && it + 1 < sweeps;               // two
             auto run = [&](hipStream_t st, int zf, int zl, int second = -1) {
-                if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape, second);
+                if (three) launch_triple(arr[src], arr[rhs], arr[dst], b, a, inv_c, triple_alt);
+                else if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape, second);
                 else fs::launch_jacobi<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, second);
             };
             const int e = g.zh;                          // planes a neighbour needs from each boundary
@@ -401,20 +408,24 @@ struct Engine : EngineBase {
                 // single GPU: one event pair around the whole run of pair launches of this solve (an
                 // event pair per launch costs 2 % at 512^3 and 16 % at 256^3), one around a trailing
                 // single sweep; launches are counted so that time / launches is the mean launch time
-                if (two) {
-                    if (pair_span < 0) pair_span = S->span_begin(FAM_PAIR);
-                    ++pair_launches;
-                } else if (pair_span >= 0) {
+                const int fam = three ? FAM_TRIPLE : FAM_PAIR;
+                if (pair_span >= 0 && (!(two || three) || fam != span_fam)) {
                     S->span_end(pair_span, pair_launches);
                     pair_span = -1;
+                    pair_launches = 0;
                 }
-                if (two) run(S->stream, 1, g.D);
+                if (two || three) {
+                    if (pair_span < 0) { pair_span = S->span_begin(fam); span_fam = fam; }
+                    ++pair_launches;
+                }
+                if (two || three) run(S->stream, 1, g.D);
                 else {
                     ScopedSpan sp(S, FAM_SWEEP);
                     run(S->stream, 1, g.D);
                 }
             }
             if (two) ++it;
+            if (three) it += 2;
             if (src_temp) held[src] = false;
             src = dst;
             src_temp = true;
@@ -423,6 +434,12 @@ struct Engine : EngineBase {
         if (!src_temp) held[src] = true;
         *result = src;
         return FS_OK;
+    }
+
+    void launch_triple(const T* src_, const T* rhs_, T* dst_, int b, T a, T inv_c, int alt)
+    {
+        if constexpr (std::is_same<T, float>::value)
+            fs::launch_jacobi_triple(S->stream, g, src_, rhs_, dst_, kill, b, a, inv_c, alt);
     }
 
     // Times the candidate launch plans of the pair kernel on this grid -- workgroup shape x the three
@@ -452,6 +469,24 @@ struct Engine : EngineBase {
                 }
                 if (ms < best) { best = ms; pair_shape = cand; }
             }
+        // three sweeps per pass, where the kernel exists for this grid: keep it if a sweep costs less
+        triple_alt = -1;
+        if (fs::triple_supported<T>(g, sc)) {
+            float best3 = 1e30f;
+            int alt3 = -1;
+            for (int alt = 0; alt < 3; ++alt) {
+                float ms = 1e30f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    HIP_TRY(hipEventRecord(e0, S->stream));
+                    launch_triple(arr[src], arr[rhs], arr[tmp], b, a, inv_c, alt);
+                    HIP_TRY(hipEventRecord(e1, S->stream));
+                    HIP_TRY(hipEventSynchronize(e1));
+                    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                }
+                if (ms < best3) { best3 = ms; alt3 = alt; }
+            }
+            if (fs::sweep_tune().fuse >= 4 || best3 / 3.0f < best / 2.0f) triple_alt = alt3;   // fuse 4: force (tests, tuning)
+        }
         hipEventDestroy(e0);
         hipEventDestroy(e1);
         held[tmp] = false;
@@ -765,6 +800,7 @@ struct Engine : EngineBase {
     }
 
     int tuned_shape() const override { return pair_shape; }
+    int tuned_triple() const override { return triple_alt; }
 
     int apply_solid_cells(const int* cells, long n) override
     {
@@ -1013,7 +1049,7 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         fs::sweep_tune().abl = atoi(value);
     } else if (k == "sweep_fuse") {
         int f = atoi(value);
-        if (f != 1 && f != 2) return fail(FS_EINVAL, "sweep_fuse: 1 | 2");
+        if (f < 1 || f > 4) return fail(FS_EINVAL, "sweep_fuse: 1 | 2 | 3 | 4");
         fs::sweep_tune().fuse = f;
     } else if (k == "project_kernels") {
         if (v == "cell") fs::sweep_tune().project_cell = 1;
@@ -1039,6 +1075,7 @@ int fs_get_int(fs_sim* s, const char* name, int* out)
     else if (n == "z_offset") *out = s->comm.active() ? s->comm.z_offset(s->D) : 0;
     else if (n == "last_advect_reach") *out = s->last_reach;
     else if (n == "pair_shape") *out = s->eng ? s->eng->tuned_shape() : -1;
+    else if (n == "triple_plan") *out = s->eng ? s->eng->tuned_triple() : -1;
     else return fail(FS_EINVAL, "unknown int member '%s'", name);
     return FS_OK;
 }

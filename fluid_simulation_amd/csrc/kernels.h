@@ -44,7 +44,8 @@ struct SweepTune {
     int zc_len = 0;           // planes per z chunk; 0 = derive from target_blocks
     int target_blocks = 2048; // aim for about this many workgroups per launch
     int abl = 0;
-    int fuse = 2;             // sweeps fused per pass over memory (1 = never fuse, 2 = pair kernel)
+    int fuse = 2;             // sweeps fused per pass over memory: 1 never, 2 pair kernel (default), 3 also time the
+                              // experimental triple kernel per grid and use it where it wins, 4 use it wherever it exists
     int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic
     int project_cell = 0;     // 1 = per-cell divergence/gradient kernels instead of the z-marching ones
     int pair_shape = 0;       // >0 forces a pair-kernel workgroup shape (1 = 8, 2 = 10, 3 = 16 waves); 0 = timed choice
@@ -67,6 +68,12 @@ template <class T>
 void launch_jacobi_pair(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
                         const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
                         int second_first = -1);
+// three sweeps per pass (fp32, whole domain on one GPU, W <= 512); `alt` picks among the launcher's
+// three best z-chunk counts like the pair launcher's candidate id >> 3
+template <class T>
+bool triple_supported(const GridDesc& g, const SlabCtx& sc);
+void launch_jacobi_triple(hipStream_t st, const GridDesc& g, const float* src, const float* rhs, float* dst,
+                          const uint8_t* flags, int b, float a, float inv_c, int alt);
 // number of workgroup shapes (0 .. count-1) worth timing for this grid; results do not depend on the shape
 template <class T>
 int pair_shape_count(const GridDesc& g);

@@ -73,6 +73,53 @@ def test_tiled_reference_order_sweep_on_ragged_grids(F, oracle_mod, shape, fp64)
     same_state(F, O, sim, ora, "tiled gs_lex %s" % (shape,))
 
 
+@pytest.mark.parametrize("shape,acc", [((14, 9, 7), 7), ((33, 21, 5), 8), ((300, 23, 9), 6), ((1, 1, 1), 3),
+                                       ((256, 30, 14), 9), ((64, 40, 33), 10)])
+def test_three_sweeps_per_pass_kernel_matches_oracle(F, oracle_mod, shape, acc):
+    """sweep_fuse=4 runs every solve as passes of three fused sweeps (experimental kernel, off by
+    default) plus a pair/single remainder; the result must be the oracle's Jacobi bit for bit,
+    with solid cells in the corners next to all six walls (the ghost mirrors of zeroed cells)."""
+    O = oracle_mod
+    W, H, D = shape
+    sim = F.Simulation(W, H, D, 1, acc=acc, solver="jacobi", quiet=1)
+    sim.set_option("sweep_fuse", "4")
+    try:
+        ora = O.Oracle(W, H, D, solver=O.JACOBI, threads=4, acc=acc)
+        m = ball_mask(W, H, D, W / 3.0, H / 2.0, D / 2.0, min(W, H, D) / 4.0)
+        m[1, 1, 1] = m[D, H, W] = True
+        m[D // 2 + 1, 1, W // 2 + 1] = True
+        sim.set_mask(m)
+        ora.set_mask(m)
+        for _ in range(2):
+            sim.run_one()
+            ora.run_one()
+        if W * H * D > 1:
+            assert sim._geti("triple_plan") >= 0
+        same_state(F, O, sim, ora, "three sweeps per pass %s" % (shape,))
+    finally:
+        sim.set_option("sweep_fuse", "2")       # the option is process-wide
+
+
+def test_three_sweeps_per_pass_kernel_full_rows(F):
+    """The same against the pair kernel on the GPU at the row widths the benchmark grids use
+    (W = 256 and 512 take the lane-aligned variant of the kernel)."""
+    for (W, H, D, acc) in [(512, 45, 31, 11), (256, 70, 20, 7), (509, 12, 40, 10)]:
+        out = []
+        for fuse in ("4", "2"):
+            sim = F.Simulation(W, H, D, 1, acc=acc, quiet=1)
+            sim.set_option("sweep_fuse", fuse)
+            m = ball_mask(W, H, D, W / 3.0, H / 2.0, D / 2.0, min(H, D) / 3.0)
+            m[1, 1, 1] = m[D, H, W] = True
+            sim.set_mask(m)
+            sim.run_one()
+            sim.run_one()
+            out.append([sim.get(f) for f in range(11)])
+            sim.set_option("sweep_fuse", "2")
+            sim.close()
+        for f in range(11):
+            assert bits_equal(out[0][f], out[1][f]), "%dx%dx%d %s" % (W, H, D, F.FIELD_NAMES[f])
+
+
 def test_odd_and_single_iteration_counts(F, oracle_mod):
     O = oracle_mod
     for acc in (1, 2, 3, 7):
