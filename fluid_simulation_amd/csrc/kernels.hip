@@ -334,8 +334,9 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 #pragma unroll
         for (int r = 0; r < RY; ++r) ld4(pz + r * g.sy, lane_on && row_in_mem(y0 + r), out[r]);
     };
-    auto fetch_plane = [&](int z, PlaneIn<T, RY>& P) {
-        fetch_core(z, P.core);
+    // the rows above/below the patch and the columns beside it are only needed of the plane that is
+    // the stencil centre: they are fetched one plane behind the cores (P.core is not used here)
+    auto fetch_side = [&](int z, PlaneIn<T, RY>& P) {
         const T* pz = src + row0 + (long)z * g.sz;
         ld4(pz - g.sy, lane_on && row_in_mem(y0 - 1), P.hb);
         ld4(pz + RY * g.sy, lane_on && row_in_mem(y0 + RY), P.ht);
@@ -441,18 +442,20 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
     };
 
     // level-0 stream, software-pipelined one plane ahead of its use (see jacobi_sweep_kernel)
-    T m[RY][4];
-    PlaneIn<T, RY> A, B, N;
+    T m[RY][4], Bc[RY][4], Nc[RY][4];
+    PlaneIn<T, RY> A, SN;                                // A: centre plane (core + sides); SN: sides of the next centre
     AuxIn<T, RY> xc, xn, xm;
     fetch_core(zl_first - 1, m);
-    fetch_plane(zl_first, A);
+    fetch_core(zl_first, A.core);
+    fetch_side(zl_first, A);
     fetch_aux(zl_first, xc);
-    fetch_plane(zl_first + 1, B);
+    fetch_core(zl_first + 1, Bc);
     xm = xc;
 
     for (int zl = zl_first; zl <= zl_last; ++zl) {
         if (zl + 1 <= zl_last) {                         // block-uniform
-            fetch_plane(zl + 2, N);                      // zl+2 <= D+1
+            fetch_core(zl + 2, Nc);                      // zl+2 <= D+1
+            fetch_side(zl + 1, SN);
             fetch_aux(zl + 1, xn);
         }
 
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
                     ym[e] = (r > 0) ? A.core[r > 0 ? r - 1 : 0][e] : A.hb[e];
                     yp[e] = (r < RY - 1) ? A.core[r < RY - 1 ? r + 1 : r][e] : A.ht[e];
                 }
-                relax4(A.core[r], left, right, ym, yp, m[r], B.core[r], xc.rhs[r], u);
+                relax4(A.core[r], left, right, ym, yp, m[r], Bc[r], xc.rhs[r], u);
                 settle4(u, xc.fl[r], st);
                 lds_put(zl, t, st);
                 if (x0 == 1) tile[zl & 3][t][3] = (b == 1) ? -u[0] : u[0];                      // ghost column x = 0
@@ -508,9 +511,12 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 #pragma unroll
         for (int r = 0; r < RY; ++r)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m[r][e] = A.core[r][e];
-        A = B;
-        B = N;
+            for (int e = 0; e < 4; ++e) {
+                m[r][e] = A.core[r][e];
+                SN.core[r][e] = Bc[r][e];
+                Bc[r][e] = Nc[r][e];
+            }
+        A = SN;
         xm = xc;
         xc = xn;
     }
