@@ -292,6 +292,17 @@ def main():
         "step_bytes_per_cell_algorithmic": 208 + 72 * acc,
         "step_roofline_frac": (208 + 72 * acc) * (elem // 4) * cells * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
     }
+    if world == 1 and not args.no_extra:
+        # the pressure solve in isolation -- `acc` sweeps (a = 1, c = 6) on the divergence
+        # field of the state the run ended in, repeated 20 times, HIP events around each repetition
+        reps = [sim.time_sweeps(0, F.PRESSURE, F.DIVERGENCE, 1.0, 6.0, acc) for _ in range(20)]
+        best, mean = min(reps), sum(reps) / len(reps)
+        out["pressure_sweep_microbench"] = {
+            "sweeps_per_repetition": acc, "repetitions": len(reps),
+            "ms_per_sweep_mean": mean, "ms_per_sweep_best": best,
+            "jacobi_iter_per_sec": 1e3 / mean,
+            "GBps_algorithmic": SWEEP_BYTES_PER_CELL * (elem // 4) * cells / (mean * 1e-3) / 1e9,
+        }
     sim.close()
 
     if world == 1 and not args.no_extra and name == "c3":
