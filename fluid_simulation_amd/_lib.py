@@ -57,6 +57,9 @@ _SIGNATURES = {
     "fs_reset_timing": (C.c_int, [C.c_void_p]),
     "fs_time_sweeps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                  C.POINTER(C.c_double)]),
+    "fs_streamlines": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double,
+                                 C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "fs_streamlines_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fs_comm_unique_id": (C.c_int, [C.c_void_p]),
     "fs_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fs_comm_selftest": (C.c_int, []),

@@ -12,6 +12,7 @@
 #include "voxelize.h"
 #include "comm.h"
 #include "dump.h"
+#include "streamlines.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -78,6 +79,7 @@ struct EngineBase {
     virtual int apply_solid_cells(const int* cells, long n) = 0;
     virtual int tuned_shape() const = 0;
     virtual int tuned_triple() const = 0;
+    virtual int streamlines(int density, double proximity, int max_length, double step_size, double threshold) = 0;
 };
 
 struct fs_sim {
@@ -112,6 +114,9 @@ struct fs_sim {
     long step_no = 0;
     long dump_frames = 0;
     fs::FrameWriter writer;      // pinned double-buffered D2H + writer thread
+    // result of the last fs_streamlines call
+    std::vector<long> sl_offsets;
+    std::vector<double> sl_points, sl_norm;
     bool dump_async = true;
 
     int span_begin(int fam)
@@ -802,6 +807,132 @@ struct Engine : EngineBase {
     int tuned_shape() const override { return pair_shape; }
     int tuned_triple() const override { return triple_alt; }
 
+    // ---- the viewer's streamlines (GUI/utils.py:118-213) -------------------------------------
+    // The device integrates every seed in both directions; what is left for the host is the
+    // reference's bookkeeping per seed: joining the two parts and the three filters.
+    int streamlines(int density, double proximity, int max_length, double step_size, double threshold) override
+    {
+        S->sl_offsets.assign(1, 0);
+        S->sl_points.clear();
+        S->sl_norm.clear();
+        if (S->comm.active()) return fail(FS_EINVAL, "streamlines are computed on a single-GPU handle");
+        if (density < 0 || max_length < 0) return fail(FS_EINVAL, "density and max_length must be >= 0");
+        const T* obs = arr[slot[FS_OBS]];
+        fs::StreamParams p;
+        p.nx = density; p.ny = density / 2; p.nz = density / 2;          // utils.py:136-138
+        p.half = max_length / 2;
+        p.step_size = step_size;
+        const int dims[3] = { g.W + 2, g.H + 2, g.D + 2 };               // config.width/height/depth
+        for (int k = 0; k < 3; ++k) {
+            p.clip_hi[k] = (double)dims[k] - 1.001;
+            p.bound_hi[k] = (double)(dims[k] - 1);
+        }
+        int* d_box = nullptr;
+        int box[6];
+        HIP_TRY(hipMalloc((void**)&d_box, sizeof box));
+        fs::launch_obs_bbox<T>(S->stream, g, obs, d_box);
+        HIP_TRY(hipMemcpyAsync(box, d_box, sizeof box, hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        hipFree(d_box);
+        if (box[0] > box[3]) return FS_OK;                               // no obstacles: no streamlines (:134-135)
+        for (int k = 0; k < 3; ++k) {
+            p.lo[k] = (double)box[k] - proximity / 10;
+            p.hi[k] = (double)box[3 + k] + proximity / 10;
+        }
+        const long nseed = (long)p.nx * p.ny * p.nz;
+        if (nseed == 0) return FS_OK;
+        // np.linspace(1, dim - 2, n): arange(n) * step + start, last element = stop
+        std::vector<double> seeds((size_t)p.nx + p.ny + p.nz);
+        {
+            const int cnt[3] = { p.nx, p.ny, p.nz };
+            size_t o = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double start = 1.0, stop = (double)(dims[k] - 2);
+                const int n = cnt[k];
+                const double step = n > 1 ? (stop - start) / (double)(n - 1) : 0.0;
+                for (int i = 0; i < n; ++i) seeds[o + i] = (double)i * step + start;
+                if (n > 1) seeds[o + n - 1] = stop;
+                o += n;
+            }
+        }
+        // utils.py:147-150: seeds outside the widened bounding box are skipped before anything else
+        std::vector<int> cand;
+        for (int iz = 0; iz < p.nz; ++iz)
+            for (int iy = 0; iy < p.ny; ++iy)
+                for (int ix = 0; ix < p.nx; ++ix) {
+                    const double sx = seeds[ix], sy = seeds[p.nx + iy], sz = seeds[(size_t)p.nx + p.ny + iz];
+                    if (sx < p.lo[0] || sx > p.hi[0] || sy < p.lo[1] || sy > p.hi[1] || sz < p.lo[2] || sz > p.hi[2]) continue;
+                    cand.push_back((iz * p.ny + iy) * p.nx + ix);
+                }
+        const long ncand = (long)cand.size();
+        if (ncand == 0) return FS_OK;
+        const size_t per = (size_t)(p.half + 1) * 3, npts = (size_t)ncand * 2 * per;
+        double *d_seeds = nullptr, *d_pts = nullptr, *d_vel = nullptr;
+        int *d_count = nullptr, *d_cand = nullptr;
+        int rc = FS_OK;
+        std::vector<double> pts, vel;
+        std::vector<int> count((size_t)ncand * 2);
+        double mx[3][3];
+        do {
+            if (hipMalloc((void**)&d_seeds, seeds.size() * 8) != hipSuccess || hipMalloc((void**)&d_pts, npts * 8) != hipSuccess ||
+                hipMalloc((void**)&d_vel, npts * 8) != hipSuccess || hipMalloc((void**)&d_count, count.size() * 4) != hipSuccess ||
+                hipMalloc((void**)&d_cand, cand.size() * 4) != hipSuccess) {
+                rc = fail(FS_ENOMEM, "streamline buffers");
+                break;
+            }
+            pts.resize(npts);
+            vel.resize(npts);
+            if (hipMemcpyAsync(d_seeds, seeds.data(), seeds.size() * 8, hipMemcpyHostToDevice, S->stream) != hipSuccess ||
+                hipMemcpyAsync(d_cand, cand.data(), cand.size() * 4, hipMemcpyHostToDevice, S->stream) != hipSuccess) { rc = fail(FS_EHIP, "seed upload"); break; }
+            fs::launch_streamlines<T>(S->stream, g, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]], obs, p, d_seeds, d_cand,
+                                      (int)ncand, d_count, d_pts, d_vel);
+            if (hipMemcpyAsync(count.data(), d_count, count.size() * 4, hipMemcpyDeviceToHost, S->stream) != hipSuccess ||
+                hipMemcpyAsync(pts.data(), d_pts, npts * 8, hipMemcpyDeviceToHost, S->stream) != hipSuccess ||
+                hipMemcpyAsync(vel.data(), d_vel, npts * 8, hipMemcpyDeviceToHost, S->stream) != hipSuccess ||
+                hipStreamSynchronize(S->stream) != hipSuccess) { rc = fail(FS_EHIP, "streamline kernel or copy failed"); break; }
+            for (int k = 0; k < 3; ++k)
+                if ((rc = stats_of(arr[slot[FS_VX + k]], mx[k]))) break;
+        } while (0);
+        hipFree(d_seeds); hipFree(d_pts); hipFree(d_vel); hipFree(d_count); hipFree(d_cand);
+        if (rc) return rc;
+        // np.max([vx, vy, vz]) + 1e-6 in the arrays' own precision (float32 for the reference's dumps)
+        const T vmax = (T)std::fmax(std::fmax(mx[0][2], mx[1][2]), mx[2][2]);
+        const double denom = (double)(T)(vmax + (T)1e-6);
+        auto norm3 = [](double a, double b, double c) { return std::sqrt((a * a + b * b) + c * c); };
+        std::vector<double> line, lvel;
+        for (long sd = 0; sd < ncand; ++sd) {
+            const int nb = count[2 * sd], nf = count[2 * sd + 1];
+            if (nb == 0) continue;                                       // seed inside an obstacle
+            const double* B = &pts[(size_t)(2 * sd) * per], *F = &pts[(size_t)(2 * sd + 1) * per];
+            const double* VB = &vel[(size_t)(2 * sd) * per], *VF = &vel[(size_t)(2 * sd + 1) * per];
+            line.clear();
+            lvel.clear();
+            for (int i = nb - 1; i >= 1; --i)                            // backward[::-1][:-1]  (:167-168)
+                for (int c = 0; c < 3; ++c) { line.push_back(B[3 * i + c]); lvel.push_back(VB[3 * i + c]); }
+            for (int i = 0; i < nf; ++i)
+                for (int c = 0; c < 3; ++c) { line.push_back(F[3 * i + c]); lvel.push_back(VF[3 * i + c]); }
+            const int n = (int)(line.size() / 3);
+            if (n <= 5) continue;                                        // :171-172
+            double max_change = 0.0;                                     // :175-181
+            for (int i = 1; i < n; ++i) {
+                const double ch = norm3(lvel[3 * i] - lvel[3 * i - 3], lvel[3 * i + 1] - lvel[3 * i - 2], lvel[3 * i + 2] - lvel[3 * i - 1]);
+                if (ch > max_change) max_change = ch;
+            }
+            if (max_change < threshold) continue;
+            bool near = false;                                           // :184-195, every third point
+            for (int i = 0; i < n && !near; i += 3)
+                near = p.lo[0] <= line[3 * i] && line[3 * i] <= p.hi[0] && p.lo[1] <= line[3 * i + 1] && line[3 * i + 1] <= p.hi[1] &&
+                       p.lo[2] <= line[3 * i + 2] && line[3 * i + 2] <= p.hi[2];
+            if (!near) continue;
+            double max_speed = 0.0;                                      // :198-205
+            for (int i = 0; i < n; ++i) max_speed = std::fmax(max_speed, norm3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]));
+            S->sl_norm.push_back(std::fmin(max_speed / denom, 1.0));
+            S->sl_points.insert(S->sl_points.end(), line.begin(), line.end());
+            S->sl_offsets.push_back((long)(S->sl_points.size() / 3));
+        }
+        return FS_OK;
+    }
+
     int apply_solid_cells(const int* cells, long n) override
     {
         // cells: device array of packed global cell ids x + y*(W+2) + z*(W+2)*(H+2)
@@ -1298,6 +1429,27 @@ int fs_time_sweeps(fs_sim* s, int b, int field, int prev, float a, float c, int 
     ENGINE_OR_RETURN(s); CHECK_B(b); CHECK_FIELD(field); CHECK_FIELD(prev);
     if (!ms_per_sweep) return fail(FS_EINVAL, "null output");
     return s->eng->time_sweeps(b, field, prev, a, c, reps, ms_per_sweep);
+}
+
+int fs_streamlines(fs_sim* s, int density, double proximity, int max_length, double step_size,
+                   double vel_change_threshold, long* n_lines, long* n_points)
+{
+    ENGINE_OR_RETURN(s);
+    int rc = s->eng->streamlines(density, proximity, max_length, step_size, vel_change_threshold);
+    if (rc) return rc;
+    if (n_lines) *n_lines = (long)s->sl_norm.size();
+    if (n_points) *n_points = (long)(s->sl_points.size() / 3);
+    return FS_OK;
+}
+
+int fs_streamlines_fetch(fs_sim* s, long* offsets, double* points, double* norm_speed)
+{
+    ENGINE_OR_RETURN(s);
+    if (s->sl_offsets.empty()) return fail(FS_EINVAL, "fs_streamlines has not been called");
+    if (offsets) memcpy(offsets, s->sl_offsets.data(), s->sl_offsets.size() * sizeof(long));
+    if (points && !s->sl_points.empty()) memcpy(points, s->sl_points.data(), s->sl_points.size() * sizeof(double));
+    if (norm_speed && !s->sl_norm.empty()) memcpy(norm_speed, s->sl_norm.data(), s->sl_norm.size() * sizeof(double));
+    return FS_OK;
 }
 
 int fs_comm_unique_id(void* id_out)

@@ -162,6 +162,20 @@ class Simulation:
     def reset_timing(self):
         check(self._L.fs_reset_timing(self._h))
 
+    def streamlines(self, density=30, proximity=2, max_length=100, step_size=0.2, vel_change_threshold=0.1):
+        """generate_streamlines of the reference's viewer (GUI/utils.py:118-213, defaults from
+        GUI/config.py:18-23) from the fields on the device.  Returns (lines, norm_speeds): a list
+        of (n_i, 3) float64 arrays in the viewer's (x, y, z) padded index space, in the reference's
+        order, and for each line the value the viewer passes to `config.density_cmap`."""
+        nl, npts = C.c_long(), C.c_long()
+        check(self._L.fs_streamlines(self._h, int(density), float(proximity), int(max_length), float(step_size),
+                                     float(vel_change_threshold), C.byref(nl), C.byref(npts)))
+        off = np.zeros(nl.value + 1, dtype=np.int64)
+        pts = np.zeros((npts.value, 3), dtype=np.float64)
+        norm = np.zeros(nl.value, dtype=np.float64)
+        check(self._L.fs_streamlines_fetch(self._h, off.ctypes.data, pts.ctypes.data, norm.ctypes.data))
+        return [pts[off[i]:off[i + 1]].copy() for i in range(nl.value)], norm
+
     def time_sweeps(self, b, field, prev, a, c, reps):
         ms = C.c_double()
         check(self._L.fs_time_sweeps(self._h, b, field, prev, a, c, reps, C.byref(ms)))

@@ -157,6 +157,25 @@ int fs_reset_timing(fs_sim* s);
  * (scratch output).  Writes the mean milliseconds per sweep. */
 int fs_time_sweeps(fs_sim* s, int b, int field, int prev, float a, float c, int reps, double* ms_per_sweep);
 
+/* ---- viewer post-processing on the device -------------------- */
+
+/* The streamlines the reference's viewer computes on the CPU for the frame it shows --
+ * generate_streamlines, GUI/utils.py:118-213, called from GUI/main_window.py:227-233 -- from the
+ * fields as they are on the device now (a dumped frame holds the same values).  Parameters are
+ * GUI/config.py:18-23: density = STREAMLINE_DENSITY (30), proximity = STREAMLINE_PROXIMITY (2),
+ * max_length = INTEGRATION_STEPS (100), step_size = INTEGRATION_STEP_SIZE (0.2),
+ * vel_change_threshold = VELOCITY_CHANGE_THRESHOLD (0.1).  Coordinates are the viewer's: indices
+ * into the padded arrays, x first.  Lines come in the reference's seed order (z, y, x loops).
+ * The result stays in the handle until the next call; *n_lines / *n_points (may be NULL) receive
+ * its size.  Single-GPU handles only. */
+int fs_streamlines(fs_sim* s, int density, double proximity, int max_length, double step_size,
+                   double vel_change_threshold, long* n_lines, long* n_points);
+/* Copies the last result: offsets[n_lines + 1] (index of each line's first point), points
+ * [3 * n_points] (x, y, z per point), norm_speed[n_lines] -- the number the viewer hands to its
+ * colour map, min(max speed along the line / (max(vx, vy, vz) + 1e-6), 1)  (utils.py:198-205).
+ * Any of the three may be NULL. */
+int fs_streamlines_fetch(fs_sim* s, long* offsets, double* points, double* norm_speed);
+
 /* ---- multi-GPU z-slabs (one process per GPU; RCCL halo exchange over xGMI) -------- */
 
 /* Size of the opaque RCCL unique id; rank 0 fills it with fs_comm_unique_id and the

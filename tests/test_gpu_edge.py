@@ -258,3 +258,36 @@ def test_create_destroy_does_not_leak_device_memory(F, tmp_path):
     assert hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(total)) == 0
     leaked = int(free0.value) - int(free1.value)
     assert leaked < 64 << 20, "device memory shrank by %d MB over 25 create/run/destroy cycles" % (leaked >> 20)
+
+
+def test_streamlines_match_the_viewer_restatement(F):
+    """fs_streamlines against oracle/streamlines_ref.py (a statement-by-statement restatement of
+    GUI/utils.py:40-213; parity unpinned: the reference module needs scikit-image and PyQt6 to import).
+    Same seeds kept, same number of points per line, coordinates to 1e-9 -- the integration is float64
+    on both sides and differs only in how numpy's BLAS dot and the device round the speed."""
+    from oracle import streamlines_ref as R
+    W, H, D = 40, 20, 18
+    sim = F.Simulation(W, H, D, 1, acc=8, quiet=1)
+    sim.set_mask(ball_mask(W, H, D, 14, 10, 9, 4.2))
+    for _ in range(25):
+        sim.run_one()
+    vx, vy, vz, obs = (np.transpose(sim.get(f), (2, 1, 0)) for f in (F.VX, F.VY, F.VZ, F.OBS))   # main_window.py:227-230
+    for density, thr in ((30, 0.1), (20, 0.0)):
+        got, gnorm = sim.streamlines(density=density, vel_change_threshold=thr)
+        want, wnorm = R.generate_streamlines(vx, vy, vz, obs, density=density, threshold=thr)
+        assert len(got) == len(want) and len(want) > 0, (len(got), len(want))
+        for a, b in zip(got, want):
+            assert a.shape == b.shape
+            assert np.allclose(a, b, rtol=0, atol=1e-9)
+        assert np.allclose(gnorm, np.array(wnorm, dtype=np.float64), rtol=1e-12, atol=0)
+    # the viewer-side drop-in takes the arrays the GUI holds (GUI/main_window.py:227-233)
+    from fluid_simulation_amd.viewer import generate_streamlines
+    lines2, colours = generate_streamlines(vx, vy, vz, obs, density=20, vel_change_threshold=0.0,
+                                           cmap=lambda v: (v, 0.0, 1.0 - v, 1.0))
+    assert len(lines2) == len(got) and all(np.array_equal(a, b) for a, b in zip(lines2, got))
+    assert len(colours) == len(got) and colours[0].shape == (4,)
+    # no obstacles: the reference returns nothing
+    empty = F.Simulation(12, 8, 6, 1, acc=2, quiet=1)
+    empty.run_one()
+    lines, norm = empty.streamlines()
+    assert lines == [] and len(norm) == 0
