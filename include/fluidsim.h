@@ -72,7 +72,9 @@ int fs_destroy(fs_sim* s);
 
 /* Options (string key/value), legal before the first step unless noted:
  *   "precision"   "fp32" (default) | "fp64"       field storage + arithmetic; before first use only
- *   "solver"      "jacobi" (default) | "gs_lex"
+ *   "solver"      "jacobi" (default; out-of-place sweeps, deterministic, multi-GPU) | "gs_lex" (the
+ *                 reference's in-place lexicographic sweep, simulation.cpp:259-271, bit-identical with
+ *                 the reference at one OpenMP thread; single GPU)
  *   "dump_dir"    directory for frame dumps, default "data" (simulation.cpp:56-60)
  *   "dump_every"  N>=1 dump every Nth step (default 1 = reference behaviour), 0 = never,
  *                 -1 = last step of fs_run only.  May be changed at any time.
@@ -84,6 +86,12 @@ int fs_destroy(fs_sim* s);
  *   "profile"     "1" brackets each kernel family with HIP events (see fs_get_timing)
  *   "elide_dead_density_solve" "1" skips diffuse(0,dens,buffer) whose result the next
  *                 advect overwrites (simulation.cpp:135-136); default "0" = do it
+ * Process-wide tuning keys that never change results (kernel selection and launch shapes):
+ *   "sweep_fuse"  "1" one solver sweep per pass over memory, "2" (default) two, "3" also time the
+ *                 experimental three-sweep kernel per grid and use it where it is faster, "4" always
+ *                 use it where it exists (fp32, single GPU, rows up to 512 cells);
+ *   "sweep_ry" "sweep_zc" "sweep_blocks" "pair_zc" "pair_shape" "project_kernels" "fuse_advect"
+ *   "overlap" -- see csrc/kernels.h (SweepTune) and tools/tune_*.py.
  */
 int fs_set_option(fs_sim* s, const char* key, const char* value);
 
