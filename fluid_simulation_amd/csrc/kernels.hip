@@ -1084,25 +1084,49 @@ void launch_set_bounds(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* 
 // Larger grids: the same order, tile by tile.  Cubic tiles of TS^3 cells are themselves swept in
 // hyperplane order I+J+L = k, one launch per k (tiles on one tile-hyperplane only touch tiles on
 // k-1, already done, and k+1, not yet started); inside a tile one workgroup walks the cell
-// hyperplanes with a barrier in between, as gs_lex_kernel does for the whole grid.
+// hyperplanes with a barrier in between, as gs_lex_kernel does for the whole grid -- on a copy of
+// the tile in LDS, so that a step costs an LDS round trip rather than one through L2.
 template <class T, int TS>
 __global__ __launch_bounds__(TS* TS) void gs_tile_kernel(GridDesc g, T* q, const T* __restrict__ rhs, T a, T inv_c, int k,
                                                           int nL)
 {
+    constexpr int E = TS + 2;
+    __shared__ T t[E][E][E];                             // the tile with one cell of its surroundings on every side
     const int I = blockIdx.x, J = blockIdx.y, L = k - I - J;
     if (L < 0 || L >= nL) return;                        // block-uniform
+    const int bx = I * TS, by = J * TS, bz = L * TS;     // tile index e <-> grid coordinate b + e
+    // Surroundings as they are in memory now: the -1 faces belong to tiles of hyperplane k-1 (already
+    // swept), the +1 faces to tiles of k+1 (not yet), exactly what the lexicographic order sees.
+    for (int i = threadIdx.x; i < E * E * E; i += TS * TS) {
+        const int ex = i % E, ey = (i / E) % E, ez = i / (E * E);
+        const int gx = bx + ex, gy = by + ey, gz = bz + ez;
+        t[ez][ey][ex] = (gx <= g.W + 1 && gy <= g.H + 1 && gz <= g.D + 1) ? q[cell(g, gx, gy, gz)] : (T)0;
+    }
     const int ly = threadIdx.x % TS, lz = threadIdx.x / TS;
-    const int y = 1 + J * TS + ly, z = 1 + L * TS + lz;
+    const int y = by + 1 + ly, z = bz + 1 + lz;
     const bool yz_on = (y <= g.H) && (z <= g.D);
+    T r[TS];
+#pragma unroll
+    for (int lx = 0; lx < TS; ++lx) r[lx] = (yz_on && bx + 1 + lx <= g.W) ? rhs[cell(g, bx + 1 + lx, y, z)] : (T)0;
+    __syncthreads();
     for (int s = 0; s < 3 * TS - 2; ++s) {
         const int lx = s - ly - lz;
-        const int x = 1 + I * TS + lx;
-        if (yz_on && lx >= 0 && lx < TS && x <= g.W) {
-            const long c = cell(g, x, y, z);
-            T nb = q[c + 1] + q[c - 1] + q[c + g.sy] + q[c - g.sy] + q[c + g.sz] + q[c - g.sz];
-            q[c] = (rhs[c] + a * nb) * inv_c;
+        if (yz_on && lx >= 0 && lx < TS && bx + 1 + lx <= g.W) {
+            T(*c)[E][E] = t;
+            const int ex = lx + 1, ey = ly + 1, ez = lz + 1;
+            T nb = c[ez][ey][ex + 1] + c[ez][ey][ex - 1] + c[ez][ey + 1][ex] + c[ez][ey - 1][ex] + c[ez + 1][ey][ex] +
+                   c[ez - 1][ey][ex];
+            T rv = (T)0;
+#pragma unroll
+            for (int j = 0; j < TS; ++j) rv = (j == lx) ? r[j] : rv;
+            c[ez][ey][ex] = (rv + a * nb) * inv_c;
         }
         __syncthreads();
+    }
+    if (yz_on) {
+#pragma unroll
+        for (int lx = 0; lx < TS; ++lx)
+            if (bx + 1 + lx <= g.W) q[cell(g, bx + 1 + lx, y, z)] = t[lz + 1][ly + 1][lx + 1];
     }
 }
 
