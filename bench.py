@@ -362,6 +362,24 @@ def main():
                                             "note": "3 steps through fs_run + one 2.7 GB frame written to " + (dump_root or "tmp")}
             s4.close()
 
+    if world == 1 and not args.no_extra and name == "c3":
+        # the N > 1 lines run config 4 (1024x512x512, strong scaling): the same workload on this one
+        # GPU, so that whoever divides the multi-GPU values has the matching single-GPU number
+        c4 = WORKLOADS["c4"]
+        s5 = F.Simulation(c4["W"], c4["H"], c4["D"], 3, acc=c4["acc"], quiet=1, dump_every=0)
+        with tempfile.TemporaryDirectory() as tmp:
+            add_obstacles(F, s5, c4, tmp)
+        s5.run_one()
+        s5.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            s5.run_one()
+        s5.sync()
+        out["extra_c4_single_gpu"] = {"workload": "c4: 1024x512x512, sphere + plate, 80 iterations",
+                                      "cells_steps_per_sec": c4["W"] * c4["H"] * c4["D"] * 3 / (time.perf_counter() - t0),
+                                      "note": "strong-scaling base of the --gpus N > 1 lines (same workload, one GPU)"}
+        s5.close()
+
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(acc, budget_s=args.cpu_budget)
     print(json.dumps(out))
