@@ -58,6 +58,17 @@ int main(int argc, char** argv)
         CHECK(fs_sync(s));
         int w;
         CHECK(fs_get_int(s, "width", &w));
+        {   // the viewer's streamlines: compute, then fetch into caller memory
+            long nl = 0, np = 0;
+            CHECK(fs_streamlines(s, 30, 2.0, 100, 0.2, 0.0, &nl, &np));
+            std::vector<long> off((size_t)nl + 1);
+            std::vector<double> pts((size_t)np * 3 + 1), norm((size_t)nl + 1);
+            CHECK(fs_streamlines_fetch(s, off.data(), pts.data(), norm.data()));
+            if (off[(size_t)nl] != np) return 6;
+        }
+        CHECK(fs_set_option(s, "sweep_fuse", "4"));     // experimental three-sweep kernel (fp32 only; fp64 keeps pairs)
+        CHECK(fs_run_one(s));
+        CHECK(fs_set_option(s, "sweep_fuse", "2"));
         CHECK(fs_set_option(s, "solver", "gs_lex"));
         CHECK(fs_run_one(s));
         CHECK(fs_destroy(s));
