@@ -89,6 +89,7 @@ struct fs_sim {
     // options
     bool fp64 = false;
     int solver = FS_SOLVER_JACOBI;
+    float omega = 1.0f;          // relaxation factor of solver=rbsor
     std::string dump_dir = "data";
     int dump_every = 1;
     unsigned voxel_seed = 1;
@@ -359,6 +360,10 @@ struct Engine : EngineBase {
         int src = cur;
         bool src_temp = false;
         const bool pairs = fs::pair_supported<T>(g, sc);
+        // solver=rbsor: every iteration is one pass of the pair kernel (its two levels are the two colours)
+        const bool rb = (S->solver == FS_SOLVER_RBSOR);
+        if (rb && !pairs) return fail(FS_EINVAL, "solver=rbsor needs rows of at most 1024 cells and sweep_fuse >= 2");
+        const T omega = rb ? (T)S->omega : (T)0;
         int pair_span = -1, span_fam = FAM_PAIR;
         long pair_launches = 0;
         if (pairs && (pair_shape < 0 || tuned_fuse != fs::sweep_tune().fuse)) {
@@ -375,11 +380,11 @@ struct Engine : EngineBase {
         for (int it = 0; it < sweeps; ++it) {
             int dst = acquire(src, rhs);
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
-            const bool three = pairs && triple_alt >= 0 && it + 2 < sweeps;   // three sweeps per pass over memory
-            const bool two = pairs && !three && it + 1 < sweeps;               // two
+            const bool three = !rb && pairs && triple_alt >= 0 && it + 2 < sweeps;   // three sweeps per pass over memory
+            const bool two = rb || (pairs && !three && it + 1 < sweeps);              // two
             auto run = [&](hipStream_t st, int zf, int zl, int second = -1) {
                 if (three) launch_triple(arr[src], arr[rhs], arr[dst], b, a, inv_c, triple_alt);
-                else if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape, second);
+                else if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape, second, omega);
                 else fs::launch_jacobi<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, second);
             };
             const int e = g.zh;                          // planes a neighbour needs from each boundary
@@ -429,7 +434,7 @@ struct Engine : EngineBase {
                     run(S->stream, 1, g.D);
                 }
             }
-            if (two) ++it;
+            if (two && !rb) ++it;
             if (three) it += 2;
             if (src_temp) held[src] = false;
             src = dst;
@@ -1147,7 +1152,12 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
     } else if (k == "solver") {
         if (v == "jacobi") s->solver = FS_SOLVER_JACOBI;
         else if (v == "gs_lex") s->solver = FS_SOLVER_GS_LEX;
-        else return fail(FS_EINVAL, "solver: jacobi | gs_lex");
+        else if (v == "rbsor") s->solver = FS_SOLVER_RBSOR;
+        else return fail(FS_EINVAL, "solver: jacobi | gs_lex | rbsor");
+    } else if (k == "sor_omega") {
+        const float om = (float)atof(value);
+        if (!(om > 0.0f && om < 2.0f)) return fail(FS_EINVAL, "sor_omega must lie in (0, 2)");
+        s->omega = om;
     } else if (k == "dump_dir") {
         s->dump_dir = v;
     } else if (k == "dump_every") {

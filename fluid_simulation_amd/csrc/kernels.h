@@ -67,7 +67,7 @@ bool pair_supported(const GridDesc& g, const SlabCtx& sc);
 template <class T>
 void launch_jacobi_pair(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
                         const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
-                        int second_first = -1);
+                        int second_first = -1, T omega = (T)0);   // omega != 0: one red-black SOR iteration instead
 // three sweeps per pass (fp32, whole domain on one GPU, W <= 512); `alt` picks among the launcher's
 // three best z-chunk counts like the pair launcher's candidate id >> 3
 template <class T>

@@ -287,12 +287,12 @@ template void launch_jacobi<double>(hipStream_t, const GridDesc&, const SlabCtx&
 // first and last level-1 row of a band have no level-2 output there (their level-1
 // neighbour row belongs to the next band); rows next to the walls use the ghost rows.
 // =====================================================================================
-template <class T, int NXW, int NYW>
+template <class T, int NXW, int NYW, bool RB>
 __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                                      const T* __restrict__ rhs, T* __restrict__ dst,
                                                                      const uint8_t* __restrict__ flags, int b, T a,
                                                                      T inv_c, int z_first, int z_last, int zc_len,
-                                                                     int z_stride, int nbands, int nblk)
+                                                                     int z_stride, int nbands, int nblk, T omega)
 {
     constexpr int RY = 2, BY = NYW * RY, TW = NXW * 256 + 8;
     // ring of four level-1 plane tiles (plane z lives in slot z & 3); column index = x + 3
@@ -382,6 +382,15 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[e] = (x0 + e <= W) ? (negate ? -u[e] : u[e]) : zero;
     };
+    // RB (solver=rbsor, not in the reference): the two levels of a pass are the two colours of one
+    // red-black SOR iteration -- level 1 moves the cells with even x+y+z (global z), level 2 the odd
+    // ones, each from its value q towards the Jacobi update r by q + omega*(r - q); the other colour
+    // keeps its value.  setBounds between the halves is what the levels do anyway.
+    auto blend4 = [&](T (&u)[4], const T (&old)[4], int y, int z, int colour) {
+        const int par = (x0 + y + z + sc.zoff + colour) & 1;          // parity of cell e = 0 relative to the colour
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = (((par + e) & 1) == 0) ? old[e] + omega * (u[e] - old[e]) : old[e];
+    };
     auto lds_row = [&](int z, int t, T (&out)[4]) {
         V4<T> q = *reinterpret_cast<const V4<T>*>(&tile[z & 3][t][x0 + 3]);
 #pragma unroll
@@ -415,6 +424,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
             lds_row(zo + 1, t, zp);
             T u[4], st[4];
             relax4(cc, left, right, ym, yp, zm, zp, X.rhs[r], u);
+            if (RB) blend4(u, cc, y, zo, 1);
             settle4(u, X.fl[r], st);
             const long base = row0 + (long)zo * g.sz + r * g.sy;
             V4<T> q;
@@ -478,6 +488,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
                     yp[e] = (r < RY - 1) ? A.core[r < RY - 1 ? r + 1 : r][e] : A.ht[e];
                 }
                 relax4(A.core[r], left, right, ym, yp, m[r], Bc[r], xc.rhs[r], u);
+                if (RB) blend4(u, A.core[r], y, zl, 0);
                 settle4(u, xc.fl[r], st);
                 lds_put(zl, t, st);
                 if (x0 == 1) tile[zl & 3][t][3] = (b == 1) ? -u[0] : u[0];                      // ghost column x = 0
@@ -524,8 +535,11 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 
 template <class T, int NXW, int NYW>
 static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                          const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt, int second_first)
+                          const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt, int second_first,
+                          T omega)
 {
+    // omega == 0: two Jacobi sweeps; otherwise one red-black SOR iteration with that relaxation factor
+    auto kernel = (omega != (T)0) ? jacobi_pair_kernel<T, NXW, NYW, true> : jacobi_pair_kernel<T, NXW, NYW, false>;
     constexpr int BY = NYW * 2;
     const SweepTune& tune = sweep_tune();
     const int planes = z_last - z_first + 1;
@@ -533,9 +547,9 @@ static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, 
     const int nbands = (g.H + (BY - 2) - 1) / (BY - 2);
     if (second_first >= 0) {
         // two equally long ranges (the slab's two boundary regions) as two chunks of one launch
-        hipLaunchKernelGGL((jacobi_pair_kernel<T, NXW, NYW>), dim3(nbands * 2), dim3(NXW * NYW * 64), 0, st, g, sc, src,
+        hipLaunchKernelGGL(kernel, dim3(nbands * 2), dim3(NXW * NYW * 64), 0, st, g, sc, src,
                            rhs, dst, flags, b, a, inv_c, z_first, second_first + planes - 1, planes,
-                           second_first - z_first, nbands, nbands * 2);
+                           second_first - z_first, nbands, nbands * 2, omega);
         return;
     }
     // z chunks: each re-reads 4 level-0 planes and recomputes 2 level-1 planes, so keep them
@@ -566,8 +580,8 @@ static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, 
     if (tune.pair_zc > 0) zc_len = tune.pair_zc < planes ? tune.pair_zc : planes;
     const int nzc = (planes + zc_len - 1) / zc_len;
     const int nblk = nbands * nzc;
-    hipLaunchKernelGGL((jacobi_pair_kernel<T, NXW, NYW>), dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, sc, src, rhs,
-                       dst, flags, b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk);
+    hipLaunchKernelGGL(kernel, dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, sc, src, rhs,
+                       dst, flags, b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk, omega);
 }
 
 template <class T>
@@ -587,7 +601,7 @@ int pair_shape_count<double>(const GridDesc&) { return 1; }
 template <>
 void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const float* src, const float* rhs,
                                float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first, int z_last,
-                               int shape, int second_first)
+                               int shape, int second_first, float omega)
 {
     // shape: 0 = 12 waves (768 threads, <=168 VGPRs), 2 = 10 waves, 1 = 8 waves, 3 = 16 waves (spills;
     // tuning tool only).  All shapes give identical results; the host driver times 0..count-1 once per
@@ -597,7 +611,7 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
     const int alt = shape >> 3;                          // which of the three best chunk counts
     shape &= 7;
     if (sweep_tune().pair_shape > 0) shape = sweep_tune().pair_shape;
-#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first)
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 2) FS_PAIR(1, 10); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 2) FS_PAIR(2, 5); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
@@ -607,14 +621,14 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
 template <>
 void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const double* src,
                                 const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
-                                int z_first, int z_last, int shape, int second_first)
+                                int z_first, int z_last, int shape, int second_first, double omega)
 {
     const int alt = shape < 0 ? 0 : (shape >> 3);
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
-    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first);
-    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first);
-    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first);
-    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first);
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
 }
 
 // =====================================================================================

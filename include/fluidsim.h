@@ -50,7 +50,10 @@ enum {
 /* Solver used by linearSolver (simulation.cpp:251-273). */
 enum {
     FS_SOLVER_JACOBI = 0,  /* ping-pong Jacobi, any grid, multi-GPU capable (default) */
-    FS_SOLVER_GS_LEX = 1   /* the reference's in-place sweep in its one-thread order; verification mode */
+    FS_SOLVER_GS_LEX = 1,  /* the reference's in-place sweep in its one-thread order; verification mode */
+    FS_SOLVER_RBSOR = 2    /* NOT the reference's arithmetic: red-black successive over-relaxation, `acc`
+                            * iterations (even x+y+z cells, then odd, setBounds after each half), relaxation
+                            * factor "sor_omega"; converges far faster per iteration; SURVEY.md 8f rank 4 */
 };
 
 /* ---- construction -------------------------------------------------------------- */
@@ -74,7 +77,9 @@ int fs_destroy(fs_sim* s);
  *   "precision"   "fp32" (default) | "fp64"       field storage + arithmetic; before first use only
  *   "solver"      "jacobi" (default; out-of-place sweeps, deterministic, multi-GPU) | "gs_lex" (the
  *                 reference's in-place lexicographic sweep, simulation.cpp:259-271, bit-identical with
- *                 the reference at one OpenMP thread; single GPU)
+ *                 the reference at one OpenMP thread; single GPU) | "rbsor" (optional red-black SOR,
+ *                 different arithmetic from the reference by design; defined by oracle/cpu_ref.c CR_RBSOR)
+ *   "sor_omega"   relaxation factor of "rbsor", in (0, 2), default 1 (= red-black Gauss-Seidel)
  *   "dump_dir"    directory for frame dumps, default "data" (simulation.cpp:56-60)
  *   "dump_every"  N>=1 dump every Nth step (default 1 = reference behaviour), 0 = never,
  *                 -1 = last step of fs_run only.  May be changed at any time.

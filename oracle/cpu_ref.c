@@ -14,7 +14,8 @@
  * them bit for bit.  tests/test_oracle_vs_ref.py repeats that live against libref.so
  * whenever it is present.
  *
- * Two solver modes:
+ * Solver modes (a third, CR_RBSOR, is the build's own optional red-black SOR and has no
+ * counterpart in the reference; see relax()):
  *   CR_GS_LEX  the reference's in-place sweep in its own loop order (x outer, y, z inner;
  *              simulation.cpp:258-270), i.e. the reference at one thread.
  *   CR_JACOBI  the same update reading all six neighbours from the previous iterate
@@ -44,7 +45,7 @@ typedef CR_REAL real;
 /* cube root in the field precision: cbrtf for float (std::cbrt(float), simulation.cpp:295) */
 #define CR_CBRT(v) (sizeof(real) == sizeof(float) ? (real)cbrtf((float)(v)) : (real)cbrt((double)(v)))
 
-enum { CR_GS_LEX = 0, CR_JACOBI = 1 };
+enum { CR_GS_LEX = 0, CR_JACOBI = 1, CR_RBSOR = 2 };
 enum { CR_DENS = 0, CR_VX, CR_VY, CR_VZ, CR_OBS, CR_P, CR_DIV, CR_VX0, CR_VY0, CR_VZ0, CR_BUF, CR_NFIELDS };
 
 typedef struct cr_sim {
@@ -52,6 +53,7 @@ typedef struct cr_sim {
     int steps, speed, sweeps; /* iter, speed, acc */
     float dt, diff, visc;
     int solver;
+    float omega;              /* CR_RBSOR only */
     size_t n;                 /* padded cell count (simulation.cpp:35) */
     size_t sy, sz;            /* strides: idx = x + y*sy + z*sz (simulation.h:9) */
     real* f[CR_NFIELDS];
@@ -70,6 +72,7 @@ cr_sim* cr_create(int w, int h, int d, int iter, int speed, float dt, float diff
     s->steps = iter; s->speed = speed; s->sweeps = acc;
     s->dt = dt; s->diff = diff; s->visc = visc;
     s->solver = CR_GS_LEX;
+    s->omega = 1.0f;
     s->sy = (size_t)w + 2;
     s->sz = s->sy * ((size_t)h + 2);
     s->n = s->sz * ((size_t)d + 2);
@@ -90,6 +93,7 @@ void cr_destroy(cr_sim* s)
 }
 
 void cr_set_solver(cr_sim* s, int mode) { s->solver = mode; }
+void cr_set_omega(cr_sim* s, float omega) { s->omega = omega; }
 int cr_real_bytes(void) { return (int)sizeof(real); }
 long cr_size(cr_sim* s) { return (long)s->n; }
 
@@ -182,6 +186,28 @@ static void relax(cr_sim* s, int b, real* q, const real* rhs, real a, real c)
     const real inv_c = (real)1 / c;                    /* :257 */
 
     for (int it = 0; it < s->sweeps; ++it) {
+        if (s->solver == CR_RBSOR) {
+            /* NOT in the reference: the build's optional solver mode, defined
+             * here.  One iteration = the cells with even x+y+z, then those with odd x+y+z, each
+             * half followed by the reference's setBounds; a cell moves from its value q towards
+             * the reference's update r by q + omega*(r - q).  Cells of one colour do not neighbour
+             * each other, so the in-place loop has no ordering freedom. */
+            const real om = (real)s->omega;
+            for (int colour = 0; colour < 2; ++colour) {
+#pragma omp parallel for collapse(2) schedule(static)
+                for (int z = 1; z <= D; ++z)
+                    for (int y = 1; y <= H; ++y)
+                        for (int x = 1; x <= W; ++x) {
+                            if (((x + y + z) & 1) != colour) continue;
+                            size_t c = AT(s, x, y, z);
+                            real nb = q[c + 1] + q[c - 1] + q[c + sy] + q[c - sy] + q[c + sz] + q[c - sz];
+                            real r = (rhs[c] + a * nb) * inv_c;
+                            q[c] = q[c] + om * (r - q[c]);
+                        }
+                enforce_bounds(s, b, q);
+            }
+            continue;
+        }
         if (s->solver == CR_GS_LEX) {
             /* reference traversal: x outermost, z innermost, updated in place (:260-262).
              * With >1 thread this is the same chunked race the reference has. */

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DENS, VX, VY, VZ, OBS, P, DIV, VX0, VY0, VZ0, BUF = range(11)
 FIELD_NAMES = ["dens", "v_x", "v_y", "v_z", "obs", "pressure", "divergence",
                "v_x_prev", "v_y_prev", "v_z_prev", "buffer"]
-GS_LEX, JACOBI = 0, 1
+GS_LEX, JACOBI, RBSOR = 0, 1, 2
 
 
 def build(force=False):
@@ -144,16 +144,19 @@ class _Sim:
 
 
 class Oracle(_Sim):
-    """The C restatement.  solver = GS_LEX (reference order) or JACOBI."""
+    """The C restatement.  solver = GS_LEX (reference order), JACOBI, or RBSOR (the build's own
+    optional red-black SOR, relaxation factor `omega`; not in the reference)."""
     prefix = "cr_"
 
-    def __init__(self, w, h, d, solver=GS_LEX, fp64=False, threads=None, **kw):
+    def __init__(self, w, h, d, solver=GS_LEX, fp64=False, threads=None, omega=1.0, **kw):
         lib = _load("libcpu_ref64.so" if fp64 else "libcpu_ref.so")
         self.dtype = np.float64 if fp64 else np.float32
         super().__init__(lib, w, h, d, **kw)
         # GS_LEX is only the reference's one-thread order at one thread; Jacobi is thread-independent
         self.threads = threads if threads is not None else (1 if solver == GS_LEX else default_threads())
         self._call("set_solver", C.c_int(solver))
+        if solver == RBSOR:
+            self._call("set_omega", C.c_float(omega))
 
     def load_stl(self, path, scale=0.8, rot=(0.0, 0.0, 0.0), translate=(0.0, 0.0, 0.0), seed=1):
         return self._call("load_stl", C.c_char_p(os.fsencode(path)), C.c_float(scale),

@@ -23,8 +23,10 @@ def main():
     W, H, D, acc, steps = (int(v) for v in sys.argv[5:10])
     stl = sys.argv[10] if len(sys.argv) > 10 else ""
     precision = sys.argv[11] if len(sys.argv) > 11 else "fp32"
+    solver = sys.argv[12] if len(sys.argv) > 12 else "jacobi"
+    extra = {"sor_omega": 1.6} if solver == "rbsor" else {}
     sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_dir=os.path.join(outdir, "data"), dump_every=1,
-                       voxel_seed=77, debug_poison_gather=1, precision=precision)
+                       voxel_seed=77, debug_poison_gather=1, precision=precision, solver=solver, **extra)
     if nranks > 1:
         sim.comm_init(rank, nranks, open(idfile, "rb").read())
     Dl, zoff = sim.local_depth, sim.z_offset

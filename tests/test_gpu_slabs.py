@@ -64,10 +64,13 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D):
         assert np.array_equal(a, b), fn
 
 
-@pytest.mark.parametrize("W,H,D,nranks,precision", [(300, 9, 24, 2, "fp32"), (20, 12, 16, 2, "fp64"), (520, 7, 36, 3, "fp32")])
-def test_slabs_wide_rows_and_fp64(tmp_path, W, H, D, nranks, precision):
-    """More than one 256-cell chunk per row (pair-kernel shapes 2xN / 3x4 on a slab) and fp64 fields."""
-    args = [W, H, D, 4, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision]
+@pytest.mark.parametrize("W,H,D,nranks,precision,solver",
+                         [(300, 9, 24, 2, "fp32", "jacobi"), (20, 12, 16, 2, "fp64", "jacobi"), (520, 7, 36, 3, "fp32", "jacobi"),
+                          (24, 11, 32, 2, "fp32", "rbsor"), (20, 9, 12, 3, "fp64", "rbsor")])
+def test_slabs_wide_rows_and_fp64(tmp_path, W, H, D, nranks, precision, solver):
+    """More than one 256-cell chunk per row (pair-kernel shapes 2xN / 3x4 on a slab), fp64 fields, and the
+    optional red-black SOR solver (cell colour follows the global z, so slabs must agree with one GPU)."""
+    args = [W, H, D, 4, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision, solver]
     ref_dir = run_ranks(str(tmp_path), 1, args)
     par_dir = run_ranks(str(tmp_path), nranks, args)
     ref = np.load(os.path.join(ref_dir, "rank0.npz"))

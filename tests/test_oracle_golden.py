@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, bits_equal, load_golden, unpack_mask
+from conftest import GOLDEN, ball_mask, bits_equal, load_golden, unpack_mask
 
 G1 = ["g1_16c_empty_acc4", "g1_24x16x12_ball_acc20", "g1_12x10x8_wall_acc1", "g1_20x12x16_voxel_acc7",
       "g1_32c_ball_acc6"]
@@ -154,3 +154,32 @@ def test_stock_run_first_40_frames_digest(oracle_mod, tmp_path):
             h.update((tmp_path / (fn + ".bin")).read_bytes())
     for fn, h in hashes.items():
         assert h.hexdigest() == meta["files"][fn]["sha256_first_40_frames"], fn
+
+
+def test_red_black_sor_oracle_is_thread_independent(oracle_mod):
+    """CR_RBSOR is the build's own optional solver, not a restatement of reference code (no goldens can
+    exist); what the CPU suite can pin is that its in-place colour loops have no ordering freedom: one
+    thread and four threads give the same bits, and omega = 1 after many iterations solves the same
+    equation as Jacobi (same fixed point)."""
+    O = oracle_mod
+    W, H, D = 13, 9, 7
+    m = ball_mask(W, H, D, 5, 4, 3, 2.0)
+    runs = []
+    for threads in (1, 4):
+        o = O.Oracle(W, H, D, solver=O.RBSOR, omega=1.7, threads=threads, acc=6)
+        o.set_mask(m)
+        for _ in range(3):
+            o.run_one()
+        runs.append([o.get(f) for f in range(11)])
+    for a, b in zip(*runs):
+        assert bits_equal(a, b)
+    # same fixed point as Jacobi: solve one diffusion equation to convergence both ways
+    rng = np.random.default_rng(5)
+    x0 = rng.standard_normal((D + 2, H + 2, W + 2)).astype(np.float32)
+    sols = []
+    for solver, acc, kw in ((O.JACOBI, 400, {}), (O.RBSOR, 200, {"omega": 1.0})):
+        o = O.Oracle(W, H, D, solver=solver, threads=2, acc=acc, **kw)
+        o.set(O.VY0, x0)
+        o.linear_solver(0, O.VY, O.VY0, 0.8, 1 + 6 * 0.8)
+        sols.append(o.get(O.VY)[1:-1, 1:-1, 1:-1])
+    assert np.allclose(sols[0], sols[1], rtol=0, atol=2e-6)
