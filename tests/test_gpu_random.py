@@ -71,3 +71,37 @@ def test_random_fp64_runs_match_oracle(mods, dims, acc, seed):
     for f in range(11):
         assert bits_equal(sim.get(f), ora.get(f)), (dims, acc, F.FIELD_NAMES[f])
     sim.close()
+
+
+@settings(max_examples=24, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture], derandomize=True)
+@given(dims=st.tuples(st.one_of(st.integers(1, 40), st.integers(250, 330)), st.one_of(st.integers(1, 12), st.integers(20, 40)),
+                     st.integers(1, 28)), acc=st.integers(1, 10),
+       mode=st.sampled_from(["triple", "rbsor"]), omega=st.sampled_from([0.7, 1.0, 1.5, 1.9]),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_random_runs_of_the_optional_kernels_match_oracle(mods, dims, acc, mode, omega, seed):
+    """The two non-default solver paths under random grids and obstacle sets: the experimental
+    three-sweeps-per-pass kernel (sweep_fuse=4; must equal plain Jacobi) and the red-black SOR mode
+    (must equal its oracle definition), random solids including cells on the walls."""
+    F, O = mods
+    W, H, D = dims
+    rng = np.random.default_rng(seed)
+    if mode == "triple":
+        sim = F.Simulation(W, H, D, 1, acc=acc, quiet=1)
+        sim.set_option("sweep_fuse", "4")
+        ora = O.Oracle(W, H, D, solver=O.JACOBI, acc=acc)
+    else:
+        sim = F.Simulation(W, H, D, 1, acc=acc, solver="rbsor", sor_omega=omega, quiet=1)
+        ora = O.Oracle(W, H, D, solver=O.RBSOR, omega=omega, acc=acc)
+    try:
+        mask = np.zeros((D + 2, H + 2, W + 2), dtype=bool)
+        mask[1:-1, 1:-1, 1:-1] = rng.random((D, H, W)) < rng.choice([0.0, 0.04, 0.25])
+        sim.set_mask(mask)
+        ora.set_mask(mask)
+        for _ in range(2):
+            sim.run_one()
+            ora.run_one()
+        for f in range(11):
+            assert bits_equal(sim.get(f), ora.get(f)), (dims, acc, mode, omega, F.FIELD_NAMES[f])
+    finally:
+        sim.set_option("sweep_fuse", "2")
+        sim.close()
