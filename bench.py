@@ -276,6 +276,7 @@ def main():
             "parallelism": ("z-slabs x%d, %s" % (world, "REHEARSAL over host shared memory (not a result)" if rehearsal
                                                   else "RCCL halo exchange over xGMI")) if world > 1 else "single GPU",
             "voxelizer_points_added": added,
+            "halo_transport": sim.comm_transport(),
         },
         "jacobi_iter_per_sec": iters_per_sec,
         "roofline": {

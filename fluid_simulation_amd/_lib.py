@@ -63,6 +63,7 @@ _SIGNATURES = {
     "fs_comm_unique_id": (C.c_int, [C.c_void_p]),
     "fs_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fs_comm_selftest": (C.c_int, []),
+    "fs_comm_transport": (C.c_char_p, [C.c_void_p]),
     "fs_last_error": (C.c_char_p, []),
     "fs_version": (C.c_char_p, []),
 }

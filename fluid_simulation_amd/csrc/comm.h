@@ -33,6 +33,7 @@ namespace fs {
 
 struct RcclApi {
     void* lib = nullptr;
+    std::string path;                    // what was dlopen'ed (diagnostics)
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -63,10 +64,10 @@ struct RcclApi {
         const char* names[] = { "librccl.so.1", "librccl.so" };
         if (!dir.empty())
             for (const char* n : names)
-                if ((api.lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL))) break;
+                if ((api.lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL))) { api.path = dir + n; break; }
         if (!api.lib)
             for (const char* n : names)
-                if ((api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+                if ((api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) { api.path = n; break; }
         if (!api.lib) {
             if (err) *err = std::string("cannot load RCCL: ") + dlerror();
             return api;
@@ -181,6 +182,11 @@ struct Comm {
     std::string err;
 
     bool active() const { return nranks > 1; }
+    const char* transport_name() const
+    {
+        return null_transport ? "none (FSNULL: timing only)" : shm ? "host shared memory (FSSHM: development)" :
+               api ? api->path.c_str() : "none";
+    }
     const char* last_error() const { return err.c_str(); }
     int local_depth(int D) const { return D / nranks; }
     int z_offset(int D) const { return rank * (D / nranks); }

@@ -1491,7 +1491,15 @@ int fs_comm_init(fs_sim* s, int rank, int nranks, const void* id)
     if (nranks == 1) return FS_OK;
     hipSetDevice(s->device);
     if (s->comm.init(rank, nranks, id)) return fail(FS_ECOMM, "%s", s->comm.last_error());
+    if (rank == 0 && !s->quiet)          // one line of provenance for multi-GPU logs
+        fprintf(stderr, "fluidsim: %d z-slabs of %d planes, halo transport: %s\n", nranks, s->D / nranks, s->comm.transport_name());
     return FS_OK;
+}
+
+const char* fs_comm_transport(fs_sim* s)
+{
+    if (!s) return "";
+    return s->comm.active() ? s->comm.transport_name() : "single GPU";
 }
 
 }  // extern "C"

@@ -181,6 +181,9 @@ class Simulation:
         check(self._L.fs_time_sweeps(self._h, b, field, prev, a, c, reps, C.byref(ms)))
         return ms.value
 
+    def comm_transport(self):
+        return (self._L.fs_comm_transport(self._h) or b"").decode(errors="replace")
+
     def comm_init(self, rank, nranks, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
         check(self._L.fs_comm_init(self._h, rank, nranks, buf))

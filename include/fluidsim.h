@@ -204,6 +204,11 @@ int fs_comm_init(fs_sim* s, int rank, int nranks, const void* id);
  * A plumbing check for machines with a single GPU. */
 int fs_comm_selftest(void);
 
+/* What carries the halo planes of this handle: "single GPU", or the path of the RCCL library that was
+ * loaded (it must be the one next to the HIP runtime the process runs on), or the name of a
+ * development transport.  The string belongs to the handle. */
+const char* fs_comm_transport(fs_sim* s);
+
 const char* fs_last_error(void);
 const char* fs_version(void);
 
