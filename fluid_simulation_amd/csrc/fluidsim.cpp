@@ -822,6 +822,9 @@ struct Engine : EngineBase {
         S->sl_norm.clear();
         if (S->comm.active()) return fail(FS_EINVAL, "streamlines are computed on a single-GPU handle");
         if (density < 0 || max_length < 0) return fail(FS_EINVAL, "density and max_length must be >= 0");
+        if (density > 4096 || max_length > 1000000) return fail(FS_EINVAL, "density <= 4096 and max_length <= 1e6, please");
+        if (!(step_size == step_size) || !(proximity == proximity) || !(threshold == threshold))
+            return fail(FS_EINVAL, "streamline parameters must not be NaN");
         const T* obs = arr[slot[FS_OBS]];
         fs::StreamParams p;
         p.nx = density; p.ny = density / 2; p.nz = density / 2;          // utils.py:136-138
@@ -872,6 +875,8 @@ struct Engine : EngineBase {
         const long ncand = (long)cand.size();
         if (ncand == 0) return FS_OK;
         const size_t per = (size_t)(p.half + 1) * 3, npts = (size_t)ncand * 2 * per;
+        if (npts > ((size_t)1 << 29))                    // 2 x 4 GiB of points and velocities: split the call instead
+            return fail(FS_ENOMEM, "%ld seeds x %d steps is more than one call should integrate; lower density or max_length", ncand, max_length);
         double *d_seeds = nullptr, *d_pts = nullptr, *d_vel = nullptr;
         int *d_count = nullptr, *d_cand = nullptr;
         int rc = FS_OK;

@@ -348,6 +348,11 @@ def test_streamlines_match_the_viewer_restatement(F):
                                            cmap=lambda v: (v, 0.0, 1.0 - v, 1.0))
     assert len(lines2) == len(got) and all(np.array_equal(a, b) for a, b in zip(lines2, got))
     assert len(colours) == len(got) and colours[0].shape == (4,)
+    # argument checks
+    for bad in (dict(density=-1), dict(max_length=-2), dict(density=5000), dict(step_size=float("nan"))):
+        with pytest.raises(F.FluidsimError):
+            sim.streamlines(**bad)
+    assert sim.streamlines(density=0) [0] == [] and sim.streamlines(max_length=0)[0] == []
     # no obstacles: the reference returns nothing
     empty = F.Simulation(12, 8, 6, 1, acc=2, quiet=1)
     empty.run_one()
