@@ -44,8 +44,8 @@ struct SweepTune {
     int zc_len = 0;           // planes per z chunk; 0 = derive from target_blocks
     int target_blocks = 2048; // aim for about this many workgroups per launch
     int abl = 0;
-    int fuse = 2;             // sweeps fused per pass over memory: 1 never, 2 pair kernel (default), 3 also time the
-                              // experimental triple kernel per grid and use it where it wins, 4 use it wherever it exists
+    int fuse = 3;             // sweeps fused per pass over memory: 1 never, 2 pair kernel only, 3 (default) also time the
+                              // three-sweep kernel per grid and use it where a sweep costs less, 4 use it wherever it exists
     int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic
     int project_cell = 0;     // 1 = per-cell divergence/gradient kernels instead of the z-marching ones
     int pair_shape = 0;       // >0 forces a pair-kernel workgroup shape (1 = 8, 2 = 10, 3 = 16 waves); 0 = timed choice

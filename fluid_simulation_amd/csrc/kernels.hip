@@ -9,6 +9,7 @@
 // file is compiled with -ffp-contract=off, so fp32 results are bit-identical with the
 // reference's `c++ -O2` build for the same iteration order.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace fs {
@@ -300,7 +301,9 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 
     const int v = xcd_contiguous(blockIdx.x, nblk);
     const int band = v % nbands, zc = v / nbands;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // readfirstlane: the wave index is the same in all 64 lanes, but only this tells the compiler so -- rows,
+    // row pointers and every row test then live in scalar registers and branch as scalars
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wx = wave % NXW, wy = wave / NXW;
     const int W = g.W, H = g.H, D = g.D;
     const int s = band * (BY - 2);                       // tile row t <-> grid row s + t
@@ -679,7 +682,9 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g
 
     const int v = xcd_contiguous(blockIdx.x, nblk);
     const int band = v % nbands, zc = v / nbands;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // readfirstlane: the wave index is the same in all 64 lanes, but only this tells the compiler so -- rows,
+    // row pointers and every row test then live in scalar registers and branch as scalars
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wx = wave % NXW, wy = wave / NXW;
     const int W = g.W, H = g.H, D = g.D;
     const int s = band * (BY - 4);                       // tile row t <-> grid row s + t
@@ -887,7 +892,6 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g
                     if (WALLZ && zl == D) face4(u, b == 3, gz1[r]);         // ghost plane z = D+1 waits for its slot, :212-214
                 }
                 kl[PH][r] = flc[r];
-                if (RY == 2) __builtin_amdgcn_sched_barrier(0);   // keep the rows apart: interleaving them doubles the live temporaries
             }
         }
         // next plane's level-0 data, one iteration ahead.  Unconditional (a conditional load merges
@@ -914,7 +918,6 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g
                         if (WALLZ && P2 == D) face4(u, b == 3, gz2[r]);
                     }
                 }
-                if (RY == 2) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (WALLZ && zl == D) {                          // level 1's oldest slot is free now: it becomes plane D+1
@@ -934,7 +937,6 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g
                     next_row(IC<1>{}, wyc, P3, r, L2[I0], L2[I1], L2[I2], rh, u);
                     if (lane_on) store_final(wyc, wzc, P3, r, u, kl[I1][r]);
                 }
-                if (RY == 2) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (WALLZ && P2 == D) {
@@ -1022,8 +1024,16 @@ void launch_jacobi_triple(hipStream_t st, const GridDesc& g, const float* src, c
 {
     // rows per wave: three, so that a 12-row band needs only 8 waves (2 per SIMD) and each may use up to
     // 256 VGPRs: the three levels x three planes of a wave's own cells are the register budget
-    if (g.W <= 256) launch_triple_v<1, 7, 3>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
-    else launch_triple_v<2, 4, 3>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+    static const int exp_shape = getenv("FS_EXP_SHAPE") ? atoi(getenv("FS_EXP_SHAPE")) : 0;   // development switch
+    if (g.W <= 256) {
+        if (exp_shape == 1) launch_triple_v<1, 7, 3>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        else if (exp_shape == 2) launch_triple_v<1, 11, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        else launch_triple_v<1, 10, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+    } else {
+        if (exp_shape == 1) launch_triple_v<2, 4, 3>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        else if (exp_shape == 2) launch_triple_v<2, 5, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        else launch_triple_v<2, 6, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+    }
 }
 
 // =====================================================================================
