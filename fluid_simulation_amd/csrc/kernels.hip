@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
     const int ybg = (v / nxw) % nybg;
     const int zc = v / (nxw * nybg);
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform, and the compiler may know
     const int W = g.W, H = g.H, D = g.D;
     const int y0 = 1 + (ybg * 4 + wv) * RY;
     if (y0 > H) return;                                  // wave-uniform
@@ -709,13 +709,18 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g
     // value, which makes the compiler wait for it on the spot instead of one iteration later): rows
     // outside the array are clamped to a row inside it and lanes beyond the row end read the row
     // start; what they fetch is never used for a cell that exists.
-    const unsigned colb = (lane_on ? (unsigned)x0 : 1u) * 4u;           // the only per-lane part of an address (bytes)
-    const unsigned colf = lane_on ? (unsigned)(x0 + 3) >> 2 : 1u;
-    const long plane_b = (long)g.sz * 4, row_b = (long)g.sy * 4;
-    // wave-uniform: start of row y of plane z, rows clamped into the array
-    auto row_of = [&](const T* base, int y, int z) {
-        return reinterpret_cast<const char*>(base) + (long)z * plane_b + (long)min(max(y, 0), H + 1) * row_b;
-    };
+    // Per-row byte offsets inside a plane sit in vector registers (there is room: 150 of 168), the plane
+    // pointers in scalar ones -- the scalar file is the scarce one here (100 of 102 in use, and every
+    // spilled scalar costs a v_readlane plus hazard nops on its way back).
+    const unsigned col0 = lane_on ? (unsigned)x0 : 1u;
+    auto clampy = [&](int y) { return (unsigned)min(max(y, 0), H + 1); };
+    unsigned oc[RY];                                     // bytes into a plane of T; kill byte index = (oc + 12) >> 4
+#pragma unroll
+    for (int r = 0; r < RY; ++r) oc[r] = (col0 + clampy(y0 + r) * (unsigned)g.sy) * 4u;
+    const long plane_b = (long)g.sz * 4, plane_f = (long)(g.sz >> 2), row_b = (long)g.sy * 4;
+    // rows below / above the patch: the first / last own row's offset with a wave-uniform step (0 where clamped)
+    const long step_b = (long)(clampy(y0) - clampy(y0 - 1)) * row_b, step_t = (long)(clampy(y0 + RY) - clampy(y0 + RY - 1)) * row_b;
+    auto plane_of = [&](const T* base, int z) { return reinterpret_cast<const char*>(base) + (long)z * plane_b; };   // wave-uniform
     auto ld4 = [&](const char* ptr, T (&out)[4]) {
         V4<T> q = *reinterpret_cast<const V4<T>*>(ptr);
 #pragma unroll
@@ -728,20 +733,22 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g
     unsigned flc[RY], kl[3][RY] = {};                    // (not in idle load registers: a select on those would wait for the loads)
 
     auto load_core = [&](int z, T (&out)[RY][4]) {
+        const char* sp = plane_of(src, z);
 #pragma unroll
-        for (int r = 0; r < RY; ++r) ld4(row_of(src, y0 + r, z) + colb, out[r]);
+        for (int r = 0; r < RY; ++r) ld4(sp + oc[r], out[r]);
     };
     auto load_side = [&](int z) {                        // what level 1 of plane z needs beside the wave's own cells
-        ld4(row_of(src, y0 - 1, z) + colb, hb);
-        ld4(row_of(src, y0 + RY, z) + colb, ht);
+        const char* sp = plane_of(src, z);
+        const char* rp = plane_of(rhs, z);
+        const uint8_t* fp = flags + (long)z * plane_f;
+        ld4(sp - step_b + oc[0], hb);
+        ld4(sp + step_t + oc[RY - 1], ht);
 #pragma unroll
         for (int r = 0; r < RY; ++r) {
-            const char* sp = row_of(src, y0 + r, z);
-            eL[r] = *reinterpret_cast<const T*>(sp + colb - 4);          // every lane fetches its own x neighbours:
-            eR[r] = *reinterpret_cast<const T*>(sp + colb + 16);         // no shuffles, no edge lanes
-            ld4(row_of(rhs, y0 + r, z) + colb, rcur[r]);
-            const long frow = ((long)z * g.sz + (long)min(max(y0 + r, 0), H + 1) * g.sy) >> 2;
-            flc[r] = (unsigned)flags[frow + colf];
+            eL[r] = *reinterpret_cast<const T*>(sp + oc[r] - 4);         // every lane fetches its own x neighbours:
+            eR[r] = *reinterpret_cast<const T*>(sp + oc[r] + 16);        // no shuffles, no edge lanes
+            ld4(rp + oc[r], rcur[r]);
+            flc[r] = (unsigned)fp[(oc[r] + 12u) >> 4];
         }
     };
 
@@ -836,7 +843,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g
         const int y = y0 + r;
         T st[4];
         settle4(u, fl, st);
-        char* base = reinterpret_cast<char*>(dst) + (long)zo * plane_b + (long)y * row_b + colb;
+        char* base = reinterpret_cast<char*>(dst) + (long)zo * plane_b + oc[r];
         V4<T> q;
 #pragma unroll
         for (int e = 0; e < 4; ++e) q.e[e] = st[e];
@@ -872,6 +879,11 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g
         constexpr int I0 = PH, I1 = (PH + 1) % 3, I2 = (PH + 2) % 3;
         // level-0 planes zl-1, zl, zl+1 sit in L0[I0], L0[I1], L0[I2]; level j planes
         // p-1, p (and the one computed now, p+1) in Lj[I0], Lj[I1], Lj[I2]
+        // The row offsets are made opaque once per iteration: otherwise loop strength reduction folds
+        // each (plane pointer + row offset) into its own 64-bit vector induction variable -- two VGPRs
+        // per access kept across the loop -- instead of a scalar base plus this 32-bit offset.
+#pragma unroll
+        for (int r = 0; r < RY; ++r) asm volatile("" : "+v"(oc[r]));
         if (zl <= hi1) {                                 // ---- level 1 of plane zl
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
@@ -1200,7 +1212,7 @@ __device__ __forceinline__ MarchTile<T> march_tile(const GridDesc& g, int zc_len
     const int v = xcd_contiguous(blockIdx.x, nblk);
     const int xw = v % nxw, ybg = (v / nxw) % nybg, zc = v / (nxw * nybg);
     t.lane = threadIdx.x & 63;
-    t.y0 = 1 + (ybg * 4 + (threadIdx.x >> 6)) * RY;
+    t.y0 = 1 + (ybg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RY;   // wave-uniform row: scalar tests and row pointers
     t.x0 = 1 + xw * 256 + t.lane * 4;
     t.lane_on = t.x0 <= g.W;
     t.zbeg = 1 + zc * zc_len;
@@ -1617,7 +1629,7 @@ __global__ __launch_bounds__(256) void advect_kernel(GridDesc g, SlabCtx sc, int
                                                       long prev_zshift)
 {
     const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int y = 1 + blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);   // cell_block(): a wave is one row
     const int z = 1 + blockIdx.z;
     if (x > g.W || y > g.H) return;
     const long c = cell(g, x, y, z);
@@ -1684,7 +1696,7 @@ __global__ __launch_bounds__(256) void advect_velocity_kernel(GridDesc g, SlabCt
                                                                long zshift)
 {
     const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int y = 1 + blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);   // cell_block(): a wave is one row
     const int z = 1 + blockIdx.z;
     if (x > g.W || y > g.H) return;
     const long c = cell(g, x, y, z);
