@@ -1043,8 +1043,16 @@ struct Engine : EngineBase {
         HIP_TRY(hipEventRecord(e0, S->stream));
         int src = s1, dst = s2;
         const bool pairs = fs::pair_supported<T>(g, sc);
+        if (pairs && (pair_shape < 0 || tuned_fuse != fs::sweep_tune().fuse)) {   // same launch plans as solve()
+            tuned_fuse = fs::sweep_tune().fuse;
+            int rc2 = choose_pair_shape(slot[field], slot[prev], b, (T)a, inv_c);
+            if (rc2) return rc2;
+        }
         for (int r = 0; r < reps; ++r) {
-            if (pairs && r + 1 < reps) {
+            if (pairs && triple_alt >= 0 && r + 2 < reps) {
+                launch_triple(arr[src], arr[slot[prev]], arr[dst], b, (T)a, inv_c, triple_alt);
+                r += 2;
+            } else if (pairs && r + 1 < reps) {
                 fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D, pair_shape);
                 ++r;
             } else {

@@ -14,7 +14,7 @@ import sys
 
 fetch_dir, write_dir, workload = sys.argv[1:4]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = ("jacobi_pair_kernel", "jacobi_sweep_kernel", "advect_velocity_kernel", "advect_kernel", "divergence_march_kernel",
+KEYS = ("jacobi_triple_kernel", "jacobi_pair_kernel", "jacobi_sweep_kernel", "advect_velocity_kernel", "advect_kernel", "divergence_march_kernel",
         "gradient_march_kernel", "divergence_kernel", "gradient_kernel")
 
 
