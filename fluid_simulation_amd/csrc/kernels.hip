@@ -656,12 +656,12 @@ void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const SlabCtx
 // into the register slot the missing plane would occupy (:208-214).
 // Bands overlap by four rows and z chunks by four planes.
 //
-// Status: experimental, off by default (option sweep_fuse = 3 lets the host time it against the
-// pair kernel per grid, 4 forces it).  MI355X, 512^3 fp32: 0.52 ms per pass = 0.174 ms per sweep
-// against the pair kernel's 0.165; it issues 83 M VALU instructions per pass (28 M per sweep, the
-// pair kernel 58 M) at the same 1.7 GB of HBM traffic, so memory is no longer the limit -- the
-// per-wave instruction stream is: the register budget (233 VGPRs) allows 2 waves per SIMD, and
-// a 12-wave variant with two rows per wave needs <= 168 and spills.  That is the next step.
+// Status: the host driver times it against the pair kernel once per grid (option sweep_fuse = 3,
+// the default; 4 forces it, 2 disables it) and uses it where a sweep costs less.  MI355X, fp32:
+// 512^3 0.42 ms per pass = 0.14 ms per sweep (pair kernel 0.167), 256^3 0.053 ms per pass; 12 waves
+// of two rows, 150 VGPRs, no scratch, 1.82 GB of HBM traffic per pass (4.3 TB/s: issue-bound, not
+// memory-bound).  What made the difference is written up in DESIGN.md section 4 (uniform wave index
+// through readfirstlane, scalar plane pointers + opaque 32-bit lane offsets, unpredicated loads).
 // =====================================================================================
 template <int N>
 struct IC {

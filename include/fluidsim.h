@@ -92,9 +92,10 @@ int fs_destroy(fs_sim* s);
  *   "elide_dead_density_solve" "1" skips diffuse(0,dens,buffer) whose result the next
  *                 advect overwrites (simulation.cpp:135-136); default "0" = do it
  * Process-wide tuning keys that never change results (kernel selection and launch shapes):
- *   "sweep_fuse"  "1" one solver sweep per pass over memory, "2" (default) two, "3" also time the
- *                 experimental three-sweep kernel per grid and use it where it is faster, "4" always
- *                 use it where it exists (fp32, single GPU, rows up to 512 cells);
+ *   "sweep_fuse"  "1" one solver sweep per pass over memory, "2" two, "3" (default) two or three: the
+ *                 three-sweep kernel (fp32, single GPU, rows up to 512 cells) is timed against the
+ *                 two-sweep one once per grid and used where a sweep costs less, "4" three wherever
+ *                 that kernel exists;
  *   "sweep_ry" "sweep_zc" "sweep_blocks" "pair_zc" "pair_shape" "project_kernels" "fuse_advect"
  *   "overlap" -- see csrc/kernels.h (SweepTune) and tools/tune_*.py.
  */

@@ -76,8 +76,8 @@ def test_tiled_reference_order_sweep_on_ragged_grids(F, oracle_mod, shape, fp64)
 @pytest.mark.parametrize("shape,acc", [((14, 9, 7), 7), ((33, 21, 5), 8), ((300, 23, 9), 6), ((1, 1, 1), 3),
                                        ((256, 30, 14), 9), ((64, 40, 33), 10)])
 def test_three_sweeps_per_pass_kernel_matches_oracle(F, oracle_mod, shape, acc):
-    """sweep_fuse=4 runs every solve as passes of three fused sweeps (experimental kernel, off by
-    default) plus a pair/single remainder; the result must be the oracle's Jacobi bit for bit,
+    """sweep_fuse=4 runs every solve as passes of three fused sweeps (at the default, 3, the host
+    only does so on grids where that times faster) plus a pair/single remainder; the result must be the oracle's Jacobi bit for bit,
     with solid cells in the corners next to all six walls (the ghost mirrors of zeroed cells)."""
     O = oracle_mod
     W, H, D = shape

@@ -79,8 +79,8 @@ def test_random_fp64_runs_match_oracle(mods, dims, acc, seed):
        mode=st.sampled_from(["triple", "rbsor"]), omega=st.sampled_from([0.7, 1.0, 1.5, 1.9]),
        seed=st.integers(0, 2 ** 31 - 1))
 def test_random_runs_of_the_optional_kernels_match_oracle(mods, dims, acc, mode, omega, seed):
-    """The two non-default solver paths under random grids and obstacle sets: the experimental
-    three-sweeps-per-pass kernel (sweep_fuse=4; must equal plain Jacobi) and the red-black SOR mode
+    """Two solver paths the small default-run grids rarely take, under random grids and obstacle sets:
+    the three-sweeps-per-pass kernel forced on (sweep_fuse=4; must equal plain Jacobi) and the red-black SOR mode
     (must equal its oracle definition), random solids including cells on the walls."""
     F, O = mods
     W, H, D = dims

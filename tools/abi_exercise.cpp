@@ -66,7 +66,7 @@ int main(int argc, char** argv)
             CHECK(fs_streamlines_fetch(s, off.data(), pts.data(), norm.data()));
             if (off[(size_t)nl] != np) return 6;
         }
-        CHECK(fs_set_option(s, "sweep_fuse", "4"));     // experimental three-sweep kernel (fp32 only; fp64 keeps pairs)
+        CHECK(fs_set_option(s, "sweep_fuse", "4"));     // force the three-sweep kernel (fp32 only; fp64 keeps pairs)
         CHECK(fs_run_one(s));
         CHECK(fs_set_option(s, "sweep_fuse", "2"));
         CHECK(fs_set_option(s, "solver", "gs_lex"));
