@@ -467,18 +467,20 @@ def test_wide_thin_slab_of_the_1024x512_grid_matches_oracle(F, oracle_mod):
 
 def test_one_step_at_512_cubed_matches_oracle_bit_exact(F, oracle_mod):
     """BASELINE config 3's grid (512^3, ball + plate-like slab of solids), one whole step with
-    acc = 2 (one pair launch per solve; the oracle needs ~6.5 GB and some seconds): bit-identical."""
+    acc = 3 (one launch of the three-sweep kernel per solve -- the kernel the benchmark runs at this
+    size; the oracle needs ~6.5 GB and some seconds): bit-identical."""
     O = oracle_mod
     W = H = D = 512
     m = ball_mask(W, H, D, 128, 256, 256, 60)
     m[150:360, 180:330, 320:332] = True
-    sim = F.Simulation(W, H, D, 1, acc=2, quiet=1)
-    ora = O.Oracle(W, H, D, solver=O.JACOBI, acc=2)
+    sim = F.Simulation(W, H, D, 1, acc=3, quiet=1)
+    ora = O.Oracle(W, H, D, solver=O.JACOBI, acc=3)
     sim.set_mask(m)
     ora.set_mask(m)
     del m
     sim.run_one()
     ora.run_one()
+    assert sim._geti("triple_plan") >= 0, "the three-sweep kernel was expected to be selected at 512^3"
     for f in (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE):
         assert_same(sim.get(f), ora.get(f), "512^3 " + F.FIELD_NAMES[f])
     sim.close()
