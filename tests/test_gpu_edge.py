@@ -97,7 +97,7 @@ def test_three_sweeps_per_pass_kernel_matches_oracle(F, oracle_mod, shape, acc):
             assert sim._geti("triple_plan") >= 0
         same_state(F, O, sim, ora, "three sweeps per pass %s" % (shape,))
     finally:
-        sim.set_option("sweep_fuse", "2")       # the option is process-wide
+        sim.set_option("sweep_fuse", "3")       # the option is process-wide: back to the default
 
 
 def test_three_sweeps_per_pass_kernel_full_rows(F):
@@ -114,7 +114,7 @@ def test_three_sweeps_per_pass_kernel_full_rows(F):
             sim.run_one()
             sim.run_one()
             out.append([sim.get(f) for f in range(11)])
-            sim.set_option("sweep_fuse", "2")
+            sim.set_option("sweep_fuse", "3")
             sim.close()
         for f in range(11):
             assert bits_equal(out[0][f], out[1][f]), "%dx%dx%d %s" % (W, H, D, F.FIELD_NAMES[f])

@@ -103,5 +103,5 @@ def test_random_runs_of_the_optional_kernels_match_oracle(mods, dims, acc, mode,
         for f in range(11):
             assert bits_equal(sim.get(f), ora.get(f)), (dims, acc, mode, omega, F.FIELD_NAMES[f])
     finally:
-        sim.set_option("sweep_fuse", "2")
+        sim.set_option("sweep_fuse", "3")
         sim.close()

@@ -68,7 +68,7 @@ int main(int argc, char** argv)
         }
         CHECK(fs_set_option(s, "sweep_fuse", "4"));     // force the three-sweep kernel (fp32 only; fp64 keeps pairs)
         CHECK(fs_run_one(s));
-        CHECK(fs_set_option(s, "sweep_fuse", "2"));
+        CHECK(fs_set_option(s, "sweep_fuse", "3"));
         CHECK(fs_set_option(s, "solver", "gs_lex"));
         CHECK(fs_run_one(s));
         CHECK(fs_destroy(s));
