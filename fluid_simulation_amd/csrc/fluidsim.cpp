@@ -484,17 +484,19 @@ struct Engine : EngineBase {
         if (fs::triple_supported<T>(g, sc)) {
             float best3 = 1e30f;
             int alt3 = -1;
-            for (int alt = 0; alt < 3; ++alt) {
-                float ms = 1e30f;
-                for (int rep = 0; rep < 2; ++rep) {
-                    HIP_TRY(hipEventRecord(e0, S->stream));
-                    launch_triple(arr[src], arr[rhs], arr[tmp], b, a, inv_c, alt);
-                    HIP_TRY(hipEventRecord(e1, S->stream));
-                    HIP_TRY(hipEventSynchronize(e1));
-                    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            for (int shape = 0; shape < fs::triple_shape_count(g); ++shape)
+                for (int alt = 0; alt < 3; ++alt) {
+                    const int plan = shape + 8 * alt;
+                    float ms = 1e30f;
+                    for (int rep = 0; rep < 2; ++rep) {
+                        HIP_TRY(hipEventRecord(e0, S->stream));
+                        launch_triple(arr[src], arr[rhs], arr[tmp], b, a, inv_c, plan);
+                        HIP_TRY(hipEventRecord(e1, S->stream));
+                        HIP_TRY(hipEventSynchronize(e1));
+                        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                    }
+                    if (ms < best3) { best3 = ms; alt3 = plan; }
                 }
-                if (ms < best3) { best3 = ms; alt3 = alt; }
-            }
             if (fs::sweep_tune().fuse >= 4 || best3 / 3.0f < best / 2.0f) triple_alt = alt3;   // fuse 4: force (tests, tuning)
         }
         hipEventDestroy(e0);

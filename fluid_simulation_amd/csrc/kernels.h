@@ -73,7 +73,8 @@ void launch_jacobi_pair(hipStream_t st, const GridDesc& g, const SlabCtx& sc, co
 template <class T>
 bool triple_supported(const GridDesc& g, const SlabCtx& sc);
 void launch_jacobi_triple(hipStream_t st, const GridDesc& g, const float* src, const float* rhs, float* dst,
-                          const uint8_t* flags, int b, float a, float inv_c, int alt);
+                          const uint8_t* flags, int b, float a, float inv_c, int plan);
+int triple_shape_count(const GridDesc& g);   // plan = shape (0 .. count-1) + 8 * alt (0..2)
 // number of workgroup shapes (0 .. count-1) worth timing for this grid; results do not depend on the shape
 template <class T>
 int pair_shape_count(const GridDesc& g);

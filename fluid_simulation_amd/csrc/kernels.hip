@@ -9,7 +9,6 @@
 // file is compiled with -ffp-contract=off, so fp32 results are bit-identical with the
 // reference's `c++ -O2` build for the same iteration order.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include "kernels.h"
 
 namespace fs {
@@ -1031,19 +1030,24 @@ bool triple_supported<float>(const GridDesc& g, const SlabCtx& sc)
 template <>
 bool triple_supported<double>(const GridDesc&, const SlabCtx&) { return false; }
 
+int triple_shape_count(const GridDesc& g) { return (g.W <= 256) ? 3 : 2; }
+
 void launch_jacobi_triple(hipStream_t st, const GridDesc& g, const float* src, const float* rhs, float* dst,
-                          const uint8_t* flags, int b, float a, float inv_c, int alt)
+                          const uint8_t* flags, int b, float a, float inv_c, int plan)
 {
-    // rows per wave: three, so that a 12-row band needs only 8 waves (2 per SIMD) and each may use up to
-    // 256 VGPRs: the three levels x three planes of a wave's own cells are the register budget
-    static const int exp_shape = getenv("FS_EXP_SHAPE") ? atoi(getenv("FS_EXP_SHAPE")) : 0;   // development switch
+    // plan = workgroup shape + 8 * (which of the launcher's three best z-chunk counts); all plans give the
+    // same bits, the host driver times them once per grid.  Two rows per wave throughout (three rows and
+    // 8 waves were slower: the instruction stream of a wave is what limits this kernel).  Rows up to 256
+    // cells: bands of 20, 16 or 12 rows (the smaller ones trade recomputed rows for longer z chunks and,
+    // at 12 rows, two workgroups per CU); up to 512 cells: 12 or 10 rows.
+    if (plan < 0) plan = 0;
+    const int alt = plan >> 3, shape = plan & 7;
     if (g.W <= 256) {
-        if (exp_shape == 1) launch_triple_v<1, 7, 3>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
-        else if (exp_shape == 2) launch_triple_v<1, 11, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        if (shape == 1) launch_triple_v<1, 8, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        else if (shape == 2) launch_triple_v<1, 6, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
         else launch_triple_v<1, 10, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
     } else {
-        if (exp_shape == 1) launch_triple_v<2, 4, 3>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
-        else if (exp_shape == 2) launch_triple_v<2, 5, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        if (shape == 1) launch_triple_v<2, 5, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
         else launch_triple_v<2, 6, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
     }
 }
