@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Pair (temporal-blocked) sweep kernel vs single sweeps (development tool)."""
+"""Pair and triple (temporal-blocked) sweep kernels vs single sweeps (development tool)."""
 import os
 import sys
 
@@ -28,3 +28,5 @@ run("single ry2 zc32", sweep_fuse=1, sweep_ry=2, sweep_zc=32)
 for small in (0, 2, 1):
     for zc in (0, 32, 43, 52, 64, 86, 128, 171, 256):
         run("pair shape=%d zc=%d" % (small, zc), sweep_fuse=2, pair_shape=small, pair_zc=zc)
+run("three sweeps per pass (tuned plan)", sweep_fuse=4, pair_shape=0, pair_zc=0)
+sim.set_option("sweep_fuse", "3")
