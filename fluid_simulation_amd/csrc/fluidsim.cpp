@@ -119,6 +119,7 @@ struct fs_sim {
     std::vector<long> sl_offsets;
     std::vector<double> sl_points, sl_norm;
     bool dump_async = true;
+    fs::SweepTune tune;          // launch tunables of this handle (fs_set_option sweep_* / pair_* / project_kernels)
 
     int span_begin(int fam)
     {
@@ -359,15 +360,15 @@ struct Engine : EngineBase {
         }
         int src = cur;
         bool src_temp = false;
-        const bool pairs = fs::pair_supported<T>(g, sc);
+        const bool pairs = fs::pair_supported<T>(S->tune, g, sc);
         // solver=rbsor: every iteration is one pass of the pair kernel (its two levels are the two colours)
         const bool rb = (S->solver == FS_SOLVER_RBSOR);
         if (rb && !pairs) return fail(FS_EINVAL, "solver=rbsor needs rows of at most 1024 cells and sweep_fuse >= 2");
         const T omega = rb ? (T)S->omega : (T)0;
         int pair_span = -1, span_fam = FAM_PAIR;
         long pair_launches = 0;
-        if (pairs && (pair_shape < 0 || tuned_fuse != fs::sweep_tune().fuse)) {
-            tuned_fuse = fs::sweep_tune().fuse;
+        if (pairs && (pair_shape < 0 || tuned_fuse != S->tune.fuse)) {
+            tuned_fuse = S->tune.fuse;
             int rc = choose_pair_shape(cur, rhs, b, a, inv_c);
             if (rc) return rc;
         }
@@ -384,8 +385,8 @@ struct Engine : EngineBase {
             const bool two = rb || (pairs && !three && it + 1 < sweeps);              // two
             auto run = [&](hipStream_t st, int zf, int zl, int second = -1) {
                 if (three) launch_triple(arr[src], arr[rhs], arr[dst], b, a, inv_c, triple_alt);
-                else if (two) fs::launch_jacobi_pair<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape, second, omega);
-                else fs::launch_jacobi<T>(st, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, second);
+                else if (two) fs::launch_jacobi_pair<T>(st, S->tune, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape, second, omega);
+                else fs::launch_jacobi<T>(st, S->tune, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, second);
             };
             const int e = g.zh;                          // planes a neighbour needs from each boundary
             if (S->comm.active() && S->overlap && g.D >= 2 * e + 8) {
@@ -449,7 +450,7 @@ struct Engine : EngineBase {
     void launch_triple(const T* src_, const T* rhs_, T* dst_, int b, T a, T inv_c, int alt)
     {
         if constexpr (std::is_same<T, float>::value)
-            fs::launch_jacobi_triple(S->stream, g, src_, rhs_, dst_, kill, b, a, inv_c, alt);
+            fs::launch_jacobi_triple(S->stream, S->tune, g, src_, rhs_, dst_, kill, b, a, inv_c, alt);
     }
 
     // Times the candidate launch plans of the pair kernel on this grid -- workgroup shape x the three
@@ -472,7 +473,7 @@ struct Engine : EngineBase {
                 float ms = 1e30f;
                 for (int rep = 0; rep < 2; ++rep) {
                     HIP_TRY(hipEventRecord(e0, S->stream));
-                    fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[rhs], arr[tmp], kill, b, a, inv_c, 1, g.D, cand);
+                    fs::launch_jacobi_pair<T>(S->stream, S->tune, g, sc, arr[src], arr[rhs], arr[tmp], kill, b, a, inv_c, 1, g.D, cand);
                     HIP_TRY(hipEventRecord(e1, S->stream));
                     HIP_TRY(hipEventSynchronize(e1));
                     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -481,7 +482,7 @@ struct Engine : EngineBase {
             }
         // three sweeps per pass, where the kernel exists for this grid: keep it if a sweep costs less
         triple_alt = -1;
-        if (fs::triple_supported<T>(g, sc)) {
+        if (fs::triple_supported<T>(S->tune, g, sc)) {
             float best3 = 1e30f;
             int alt3 = -1;
             for (int shape = 0; shape < fs::triple_shape_count(g); ++shape)
@@ -497,7 +498,7 @@ struct Engine : EngineBase {
                     }
                     if (ms < best3) { best3 = ms; alt3 = plan; }
                 }
-            if (fs::sweep_tune().fuse >= 4 || best3 / 3.0f < best / 2.0f) triple_alt = alt3;   // fuse 4: force (tests, tuning)
+            if (S->tune.fuse >= 4 || best3 / 3.0f < best / 2.0f) triple_alt = alt3;   // fuse 4: force (tests, tuning)
         }
         hipEventDestroy(e0);
         hipEventDestroy(e1);
@@ -564,7 +565,7 @@ struct Engine : EngineBase {
         const T h = (T)1 / host_cbrt<T>((T)(S->W * S->H * S->D));   // :295 (int product, like the reference)
         {
             ScopedSpan sp(S, FAM_DIV);
-            fs::launch_divergence<T>(S->stream, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
+            fs::launch_divergence<T>(S->stream, S->tune, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
                                      arr[slot[FS_DIVERGENCE]], arr[slot[FS_PRESSURE]], flags, (T)(-0.5) * h);
         }
         // divergence of the neighbouring slabs' boundary planes is never read (the solve only reads
@@ -577,7 +578,7 @@ struct Engine : EngineBase {
         adopt(FS_PRESSURE, res);
         {
             ScopedSpan sp(S, FAM_GRAD);
-            fs::launch_gradient<T>(S->stream, g, sc, arr[slot[FS_PRESSURE]], arr[slot[FS_VX]], arr[slot[FS_VY]],
+            fs::launch_gradient<T>(S->stream, S->tune, g, sc, arr[slot[FS_PRESSURE]], arr[slot[FS_VX]], arr[slot[FS_VY]],
                                    arr[slot[FS_VZ]], flags, h, (T)2 * h);
         }
         // the next consumer of v's z-halo planes is the divergence of the second projection
@@ -799,15 +800,18 @@ struct Engine : EngineBase {
 
     int point(int which, int x, int y, int z, float v, int set_instead) override
     {
-        // x,y are global = local; z is global and must fall into this slab to have an effect
-        int zl = z - sc.zoff;
-        if (zl < 1 || zl > g.D) return FS_OK;
+        // x,y are global = local; z is global and must fall into this slab to have an effect.
+        // The bookkeeping is the same on EVERY rank (every rank issues the same call): the slot maps
+        // must not diverge, and ensure_halos() / ensure_flags() are collectives gated on these bits --
+        // only the one-cell kernel launch depends on who owns plane z.
         int rc = unalias(which);
         if (rc) return rc;
-        long idx = (long)x + (long)y * g.sy + (long)zl * g.sz;
-        fs::launch_point_add<T>(S->stream, arr[slot[which]], idx, (T)v, set_instead);
         if (which == FS_OBS) flags_dirty = true;
         else halos_dirty = true;
+        int zl = z - sc.zoff;
+        if (zl < 1 || zl > g.D) return FS_OK;
+        long idx = (long)x + (long)y * g.sy + (long)zl * g.sz;
+        fs::launch_point_add<T>(S->stream, arr[slot[which]], idx, (T)v, set_instead);
         return FS_OK;
     }
 
@@ -1037,28 +1041,32 @@ struct Engine : EngineBase {
         int s2 = acquire(slot[field], slot[prev]);
         if (s1 < 0 || s2 < 0) return fail(FS_ENOMEM, "array pool exhausted");
         const T inv_c = (T)1 / (T)c;
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        // one untimed sweep to fault in code and scratch
-        fs::launch_jacobi<T>(S->stream, g, sc, arr[slot[field]], arr[slot[prev]], arr[s1], kill, b, (T)a, inv_c, 1, g.D);
-        HIP_TRY(hipEventRecord(e0, S->stream));
-        int src = s1, dst = s2;
-        const bool pairs = fs::pair_supported<T>(g, sc);
-        if (pairs && (pair_shape < 0 || tuned_fuse != fs::sweep_tune().fuse)) {   // same launch plans as solve()
-            tuned_fuse = fs::sweep_tune().fuse;
+        struct Release {                                   // error paths must not leak the scratch arrays or the events
+            bool* held; int a, b; hipEvent_t e0 = nullptr, e1 = nullptr;
+            ~Release() { held[a] = held[b] = false; if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+        } rel{held, s1, s2};
+        const bool pairs = fs::pair_supported<T>(S->tune, g, sc);
+        if (pairs && (pair_shape < 0 || tuned_fuse != S->tune.fuse)) {   // same launch plans as solve(); tuned BEFORE the clock starts
+            tuned_fuse = S->tune.fuse;
             int rc2 = choose_pair_shape(slot[field], slot[prev], b, (T)a, inv_c);
             if (rc2) return rc2;
         }
+        HIP_TRY(hipEventCreate(&rel.e0));
+        HIP_TRY(hipEventCreate(&rel.e1));
+        hipEvent_t e0 = rel.e0, e1 = rel.e1;
+        // one untimed sweep to fault in code and scratch
+        fs::launch_jacobi<T>(S->stream, S->tune, g, sc, arr[slot[field]], arr[slot[prev]], arr[s1], kill, b, (T)a, inv_c, 1, g.D);
+        HIP_TRY(hipEventRecord(e0, S->stream));
+        int src = s1, dst = s2;
         for (int r = 0; r < reps; ++r) {
             if (pairs && triple_alt >= 0 && r + 2 < reps) {
                 launch_triple(arr[src], arr[slot[prev]], arr[dst], b, (T)a, inv_c, triple_alt);
                 r += 2;
             } else if (pairs && r + 1 < reps) {
-                fs::launch_jacobi_pair<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D, pair_shape);
+                fs::launch_jacobi_pair<T>(S->stream, S->tune, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D, pair_shape);
                 ++r;
             } else {
-                fs::launch_jacobi<T>(S->stream, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D);
+                fs::launch_jacobi<T>(S->stream, S->tune, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D);
             }
             int t = src; src = dst; dst = t;
         }
@@ -1067,9 +1075,6 @@ struct Engine : EngineBase {
         float t = 0;
         HIP_TRY(hipEventElapsedTime(&t, e0, e1));
         *ms = (double)t / reps;
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
-        held[s1] = held[s2] = false;
         return FS_OK;
     }
 };
@@ -1196,25 +1201,25 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
     } else if (k == "sweep_ry") {
         int r = atoi(value);
         if (r != 2 && r != 4) return fail(FS_EINVAL, "sweep_ry: 2 | 4");
-        fs::sweep_tune().ry = r;
+        s->tune.ry = r;
     } else if (k == "sweep_zc") {
-        fs::sweep_tune().zc_len = atoi(value);
+        s->tune.zc_len = atoi(value);
     } else if (k == "sweep_blocks") {
-        fs::sweep_tune().target_blocks = atoi(value) > 0 ? atoi(value) : 2048;
+        s->tune.target_blocks = atoi(value) > 0 ? atoi(value) : 2048;
     } else if (k == "sweep_abl") {
-        fs::sweep_tune().abl = atoi(value);
+        s->tune.abl = atoi(value);
     } else if (k == "sweep_fuse") {
         int f = atoi(value);
         if (f < 1 || f > 4) return fail(FS_EINVAL, "sweep_fuse: 1 | 2 | 3 | 4");
-        fs::sweep_tune().fuse = f;
+        s->tune.fuse = f;
     } else if (k == "project_kernels") {
-        if (v == "cell") fs::sweep_tune().project_cell = 1;
-        else if (v == "march") fs::sweep_tune().project_cell = 0;
+        if (v == "cell") s->tune.project_cell = 1;
+        else if (v == "march") s->tune.project_cell = 0;
         else return fail(FS_EINVAL, "project_kernels: march | cell");
     } else if (k == "pair_zc") {
-        fs::sweep_tune().pair_zc = atoi(value);
+        s->tune.pair_zc = atoi(value);
     } else if (k == "pair_shape") {
-        fs::sweep_tune().pair_shape = atoi(value);
+        s->tune.pair_shape = atoi(value);
     } else {
         return fail(FS_EINVAL, "unknown option '%s'", key);
     }
@@ -1304,8 +1309,11 @@ int fs_load_stl(fs_sim* s, const char* stl_file, float scale, float rot_x, float
     fs::VoxelResult vr;
     int rc = fs::voxelize_stl(s->stream, stl_file, s->W, s->H, s->D, scale, rot_x, rot_y, rot_z, translate_x,
                               translate_y, translate_z, s->voxel_seed, s->quiet, &vr);
-    if (rc == FS_EIO) return fail(FS_EIO, "%s", vr.error.c_str());
-    if (rc) return fail(rc, "voxelizer: %s", vr.error.c_str());
+    if (rc) {                                              // every exit releases the voxelizer's device buffers
+        const std::string msg = vr.error;
+        fs::voxelize_free(&vr);
+        return rc == FS_EIO ? fail(FS_EIO, "%s", msg.c_str()) : fail(rc, "voxelizer: %s", msg.c_str());
+    }
     if (added) *added = vr.added;
     rc = s->eng->apply_solid_cells(vr.d_cells, vr.added);
     hipStreamSynchronize(s->stream);

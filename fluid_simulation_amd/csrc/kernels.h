@@ -39,6 +39,7 @@ struct SlabCtx {
 
 // Tunables of the sweep launch (set through fs_set_option "sweep_ry" / "sweep_zc" /
 // "sweep_blocks"; "sweep_abl" selects timing-only ablation builds used by tools/tune_sweep.py).
+// One instance per handle (fs_sim::tune): options never leak between handles or host threads.
 struct SweepTune {
     int ry = 2;               // rows per wave patch of the single-sweep kernel: 2 or 4
     int zc_len = 0;           // planes per z chunk; 0 = derive from target_blocks
@@ -50,12 +51,11 @@ struct SweepTune {
     int project_cell = 0;     // 1 = per-cell divergence/gradient kernels instead of the z-marching ones
     int pair_shape = 0;       // >0 forces a pair-kernel workgroup shape (1 = 8, 2 = 10, 3 = 16 waves); 0 = timed choice
 };
-SweepTune& sweep_tune();
 
 // NOTE: the sweep launchers take the KILL-byte array (launch_build_kill), not the flag bytes.
 template <class T>
-void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                   const uint8_t* kill, int b, T a, T inv_c, int z_first, int z_last, int second_first = -1);
+void launch_jacobi(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
+                   T* dst, const uint8_t* kill, int b, T a, T inv_c, int z_first, int z_last, int second_first = -1);
 // second_first >= 0: ALSO compute the equally long range starting there, in the same launch (a
 // slab's two boundary regions)
 
@@ -63,17 +63,17 @@ void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T
 // Needs W <= 1024; on a z-slab additionally two halo planes per side (g.zh == 2), current in
 // `src`, and one current halo plane of `rhs` and `flags`.
 template <class T>
-bool pair_supported(const GridDesc& g, const SlabCtx& sc);
+bool pair_supported(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc);
 template <class T>
-void launch_jacobi_pair(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                        const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
+void launch_jacobi_pair(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
+                        T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
                         int second_first = -1, T omega = (T)0);   // omega != 0: one red-black SOR iteration instead
 // three sweeps per pass (fp32, whole domain on one GPU, W <= 512); `alt` picks among the launcher's
 // three best z-chunk counts like the pair launcher's candidate id >> 3
 template <class T>
-bool triple_supported(const GridDesc& g, const SlabCtx& sc);
-void launch_jacobi_triple(hipStream_t st, const GridDesc& g, const float* src, const float* rhs, float* dst,
-                          const uint8_t* flags, int b, float a, float inv_c, int plan);
+bool triple_supported(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc);
+void launch_jacobi_triple(hipStream_t st, const SweepTune& tune, const GridDesc& g, const float* src, const float* rhs,
+                          float* dst, const uint8_t* flags, int b, float a, float inv_c, int plan);
 int triple_shape_count(const GridDesc& g);   // plan = shape (0 .. count-1) + 8 * alt (0..2)
 // number of workgroup shapes (0 .. count-1) worth timing for this grid; results do not depend on the shape
 template <class T>
@@ -87,12 +87,12 @@ template <class T>
 void launch_set_bounds(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* q, const uint8_t* flags, int b);
 
 template <class T>
-void launch_divergence(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* vx, const T* vy, const T* vz,
-                       T* div, T* p, const uint8_t* flags, T mhalf_h);
+void launch_divergence(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* vx, const T* vy,
+                       const T* vz, T* div, T* p, const uint8_t* flags, T mhalf_h);
 
 template <class T>
-void launch_gradient(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* p, T* vx, T* vy, T* vz,
-                     const uint8_t* flags, T h, T two_h);
+void launch_gradient(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* p, T* vx, T* vy,
+                     T* vz, const uint8_t* flags, T h, T two_h);
 
 // `prev_zshift` = element offset added to local indices of `prev` (0 normally; under
 // z-slabs `prev` is the all-gathered global array and the shift is zoff planes).

@@ -203,17 +203,11 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
     }
 }
 
-SweepTune& sweep_tune()
-{
-    static SweepTune t;
-    return t;
-}
-
 template <class T, int RY, int ABL>
-static void launch_jacobi_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                            const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int second_first)
+static void launch_jacobi_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
+                            const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last,
+                            int second_first)
 {
-    const SweepTune& tune = sweep_tune();
     const int nxw = (g.W + 255) / 256;
     const int nyb = (g.H + RY - 1) / RY;
     const int nybg = (nyb + 3) / 4;
@@ -241,12 +235,11 @@ static void launch_jacobi_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc
 }
 
 template <class T>
-void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                   const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int second_first)
+void launch_jacobi(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
+                   T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int second_first)
 {
     if (z_last < z_first) return;
-    const SweepTune& tune = sweep_tune();
-#define FS_GO(RY, ABL) launch_jacobi_v<T, RY, ABL>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, second_first)
+#define FS_GO(RY, ABL) launch_jacobi_v<T, RY, ABL>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, second_first)
     if (tune.abl == 0) {
         if (tune.ry == 4) FS_GO(4, 0);
         else FS_GO(2, 0);
@@ -262,10 +255,10 @@ void launch_jacobi(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T
     }
 #undef FS_GO
 }
-template void launch_jacobi<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, const float*, float*,
-                                   const uint8_t*, int, float, float, int, int, int);
-template void launch_jacobi<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, const double*, double*,
-                                    const uint8_t*, int, double, double, int, int, int);
+template void launch_jacobi<float>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, const float*, const float*,
+                                   float*, const uint8_t*, int, float, float, int, int, int);
+template void launch_jacobi<double>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, const double*,
+                                    const double*, double*, const uint8_t*, int, double, double, int, int, int);
 
 // =====================================================================================
 // Two Jacobi sweeps per pass over memory (temporal blocking), bit-identical with two
@@ -536,14 +529,13 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 }
 
 template <class T, int NXW, int NYW>
-static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs, T* dst,
-                          const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt, int second_first,
-                          T omega)
+static void launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
+                          const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt,
+                          int second_first, T omega)
 {
     // omega == 0: two Jacobi sweeps; otherwise one red-black SOR iteration with that relaxation factor
     auto kernel = (omega != (T)0) ? jacobi_pair_kernel<T, NXW, NYW, true> : jacobi_pair_kernel<T, NXW, NYW, false>;
     constexpr int BY = NYW * 2;
-    const SweepTune& tune = sweep_tune();
     const int planes = z_last - z_first + 1;
     if (planes <= 0) return;
     const int nbands = (g.H + (BY - 2) - 1) / (BY - 2);
@@ -587,13 +579,13 @@ static void launch_pair_v(hipStream_t st, const GridDesc& g, const SlabCtx& sc, 
 }
 
 template <class T>
-bool pair_supported(const GridDesc& g, const SlabCtx& sc)
+bool pair_supported(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc)
 {
     const bool whole = sc.lo_wall && sc.hi_wall;
-    return (whole || g.zh >= 2) && g.W <= 1024 && sweep_tune().fuse >= 2;
+    return (whole || g.zh >= 2) && g.W <= 1024 && tune.fuse >= 2;
 }
-template bool pair_supported<float>(const GridDesc&, const SlabCtx&);
-template bool pair_supported<double>(const GridDesc&, const SlabCtx&);
+template bool pair_supported<float>(const SweepTune&, const GridDesc&, const SlabCtx&);
+template bool pair_supported<double>(const SweepTune&, const GridDesc&, const SlabCtx&);
 
 template <>
 int pair_shape_count<float>(const GridDesc& g) { return (g.W <= 512) ? 3 : 1; }
@@ -601,9 +593,9 @@ template <>
 int pair_shape_count<double>(const GridDesc&) { return 1; }
 
 template <>
-void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const float* src, const float* rhs,
-                               float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first, int z_last,
-                               int shape, int second_first, float omega)
+void launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const float* src,
+                               const float* rhs, float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first,
+                               int z_last, int shape, int second_first, float omega)
 {
     // shape: 0 = 12 waves (768 threads, <=168 VGPRs), 2 = 10 waves, 1 = 8 waves, 3 = 16 waves (spills;
     // tuning tool only).  All shapes give identical results; the host driver times 0..count-1 once per
@@ -612,8 +604,8 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
     if (shape < 0) shape = 0;
     const int alt = shape >> 3;                          // which of the three best chunk counts
     shape &= 7;
-    if (sweep_tune().pair_shape > 0) shape = sweep_tune().pair_shape;
-#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega)
+    if (tune.pair_shape > 0) shape = tune.pair_shape;
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 2) FS_PAIR(1, 10); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 2) FS_PAIR(2, 5); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
@@ -621,16 +613,16 @@ void launch_jacobi_pair<float>(hipStream_t st, const GridDesc& g, const SlabCtx&
 #undef FS_PAIR
 }
 template <>
-void launch_jacobi_pair<double>(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const double* src,
+void launch_jacobi_pair<double>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const double* src,
                                 const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
                                 int z_first, int z_last, int shape, int second_first, double omega)
 {
     const int alt = shape < 0 ? 0 : (shape >> 3);
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
-    if (nxw == 1) launch_pair_v<double, 1, 8>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
-    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
-    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
-    else launch_pair_v<double, 4, 2>(st, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    else launch_pair_v<double, 4, 2>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
 }
 
 // =====================================================================================
@@ -983,11 +975,10 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g
 }
 
 template <int NXW, int NYW, int RY>
-static void launch_triple_v(hipStream_t st, const GridDesc& g, const float* src, const float* rhs, float* dst,
-                            const uint8_t* flags, int b, float a, float inv_c, int alt)
+static void launch_triple_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const float* src, const float* rhs,
+                            float* dst, const uint8_t* flags, int b, float a, float inv_c, int alt)
 {
     constexpr int BY = NYW * RY;
-    const SweepTune& tune = sweep_tune();
     const int planes = g.D;
     // band k outputs rows k(BY-4)+2 .. k(BY-4)+BY-3 (band 0 from row 1, the last band up to row H)
     const int nbands = (g.H <= BY - 3) ? 1 : (g.H - (BY - 3) + (BY - 4) - 1) / (BY - 4) + 1;
@@ -1023,17 +1014,17 @@ static void launch_triple_v(hipStream_t st, const GridDesc& g, const float* src,
 }
 
 template <>
-bool triple_supported<float>(const GridDesc& g, const SlabCtx& sc)
+bool triple_supported<float>(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc)
 {
-    return sc.lo_wall && sc.hi_wall && g.W <= 512 && sweep_tune().fuse >= 3;
+    return sc.lo_wall && sc.hi_wall && g.W <= 512 && tune.fuse >= 3;
 }
 template <>
-bool triple_supported<double>(const GridDesc&, const SlabCtx&) { return false; }
+bool triple_supported<double>(const SweepTune&, const GridDesc&, const SlabCtx&) { return false; }
 
 int triple_shape_count(const GridDesc& g) { return (g.W <= 256) ? 3 : 2; }
 
-void launch_jacobi_triple(hipStream_t st, const GridDesc& g, const float* src, const float* rhs, float* dst,
-                          const uint8_t* flags, int b, float a, float inv_c, int plan)
+void launch_jacobi_triple(hipStream_t st, const SweepTune& tune, const GridDesc& g, const float* src, const float* rhs,
+                          float* dst, const uint8_t* flags, int b, float a, float inv_c, int plan)
 {
     // plan = workgroup shape + 8 * (which of the launcher's three best z-chunk counts); all plans give the
     // same bits, the host driver times them once per grid.  Two rows per wave throughout (three rows and
@@ -1043,12 +1034,12 @@ void launch_jacobi_triple(hipStream_t st, const GridDesc& g, const float* src, c
     if (plan < 0) plan = 0;
     const int alt = plan >> 3, shape = plan & 7;
     if (g.W <= 256) {
-        if (shape == 1) launch_triple_v<1, 8, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
-        else if (shape == 2) launch_triple_v<1, 6, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
-        else launch_triple_v<1, 10, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        if (shape == 1) launch_triple_v<1, 8, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        else if (shape == 2) launch_triple_v<1, 6, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        else launch_triple_v<1, 10, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
     } else {
-        if (shape == 1) launch_triple_v<2, 5, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
-        else launch_triple_v<2, 6, 2>(st, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        if (shape == 1) launch_triple_v<2, 5, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
+        else launch_triple_v<2, 6, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
     }
 }
 
@@ -1542,10 +1533,10 @@ __global__ __launch_bounds__(256) void divergence_kernel(GridDesc g, SlabCtx sc,
 }
 
 template <class T>
-void launch_divergence(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* vx, const T* vy, const T* vz,
-                       T* div, T* p, const uint8_t* flags, T mhalf_h)
+void launch_divergence(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* vx, const T* vy,
+                       const T* vz, T* div, T* p, const uint8_t* flags, T mhalf_h)
 {
-    if (sweep_tune().project_cell) {
+    if (tune.project_cell) {
         hipLaunchKernelGGL((divergence_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, div, p, flags,
                            mhalf_h);
         return;
@@ -1555,10 +1546,10 @@ void launch_divergence(hipStream_t st, const GridDesc& g, const SlabCtx& sc, con
     hipLaunchKernelGGL((divergence_march_kernel<T, RY>), dim3(m.nblk), dim3(256), 0, st, g, sc, vx, vy, vz, div, p, flags,
                        mhalf_h, m.zc_len, m.nxw, m.nybg, m.nblk);
 }
-template void launch_divergence<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, const float*,
-                                       const float*, float*, float*, const uint8_t*, float);
-template void launch_divergence<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, const double*,
-                                        const double*, double*, double*, const uint8_t*, double);
+template void launch_divergence<float>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, const float*,
+                                       const float*, const float*, float*, float*, const uint8_t*, float);
+template void launch_divergence<double>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, const double*,
+                                        const double*, const double*, double*, double*, const uint8_t*, double);
 
 // =====================================================================================
 // project, part 2: v -= grad p, then setBounds(1,vx), (2,vy), (3,vz)
@@ -1601,10 +1592,10 @@ __global__ __launch_bounds__(256) void gradient_kernel(GridDesc g, SlabCtx sc, c
 }
 
 template <class T>
-void launch_gradient(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* p, T* vx, T* vy, T* vz,
-                     const uint8_t* flags, T h, T two_h)
+void launch_gradient(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* p, T* vx, T* vy,
+                     T* vz, const uint8_t* flags, T h, T two_h)
 {
-    if (sweep_tune().project_cell) {
+    if (tune.project_cell) {
         hipLaunchKernelGGL((gradient_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, p, vx, vy, vz, flags, h, two_h);
         return;
     }
@@ -1613,10 +1604,10 @@ void launch_gradient(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const
     hipLaunchKernelGGL((gradient_march_kernel<T, RY>), dim3(m.nblk), dim3(256), 0, st, g, sc, p, vx, vy, vz, flags, h, two_h,
                        m.zc_len, m.nxw, m.nybg, m.nblk);
 }
-template void launch_gradient<float>(hipStream_t, const GridDesc&, const SlabCtx&, const float*, float*, float*, float*,
-                                     const uint8_t*, float, float);
-template void launch_gradient<double>(hipStream_t, const GridDesc&, const SlabCtx&, const double*, double*, double*,
-                                      double*, const uint8_t*, double, double);
+template void launch_gradient<float>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, const float*, float*,
+                                     float*, float*, const uint8_t*, float, float);
+template void launch_gradient<double>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, const double*,
+                                      double*, double*, double*, const uint8_t*, double, double);
 
 // =====================================================================================
 // Semi-Lagrangian advection + setBounds(b, field)   simulation.cpp:367-424

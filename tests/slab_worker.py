@@ -45,6 +45,14 @@ def main():
     sim.set_option("dump_every", 0)
     sim.run_one()
     sim.run_one()
+    # edits that fall into ONE rank's planes only -- an interior plane, then a slab-boundary plane whose
+    # neighbour holds a halo copy: the dirty-halo bookkeeping must stay rank-symmetric (collectives pair up)
+    for zb in (2, D // 2, D // 2 + 1, max(1, D // 3)):
+        sim.addDensity(7, 3, zb, 0.5)
+        sim.setVelocity(4, 6, zb, -1.0, 0.75, 0.5)
+        sim.run_one()
+    sim.addObstacle(11, 5, D // 2)
+    sim.run_one()
     out = {F.FIELD_NAMES[f]: sim.get(f) for f in (F.DENS, F.VX, F.VY, F.VZ, F.OBS, F.PRESSURE)}
     stats = np.array(sim.stats(F.DENS) + sim.stats(F.VX))
     reach = sim._geti("last_advect_reach")
