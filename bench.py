@@ -46,6 +46,29 @@ def add_obstacles(F, sim, cfg, tmp):
     return added
 
 
+def kernels_sha():
+    """Identity of the kernel sources a PMC measurement belongs to (profiles/sweep_traffic.json stamps)."""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("kernels.hip", "kernels.h"):
+        with open(os.path.join(ROOT, "fluid_simulation_amd", "csrc", fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pressure_residual(p, div, obs):
+    """|| div + sum of the six neighbours - 6 p || over fluid cells, relative to || div || (the equation
+    linearSolver(0, p, div, 1, 6) iterates on, simulation.cpp:320): how far a fixed iteration count got."""
+    import numpy as np
+    p = p.astype(np.float64)
+    c = p[1:-1, 1:-1, 1:-1]
+    nb = (p[1:-1, 1:-1, 2:] + p[1:-1, 1:-1, :-2] + p[1:-1, 2:, 1:-1] + p[1:-1, :-2, 1:-1] + p[2:, 1:-1, 1:-1] + p[:-2, 1:-1, 1:-1])
+    r = div[1:-1, 1:-1, 1:-1].astype(np.float64) + nb - 6.0 * c
+    fluid = obs[1:-1, 1:-1, 1:-1] < 0.5
+    d = div[1:-1, 1:-1, 1:-1][fluid].astype(np.float64)
+    return float(np.sqrt((r[fluid] ** 2).sum()) / max(1e-300, np.sqrt((d ** 2).sum())))
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -56,50 +79,77 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(acc, budget_s=12.0):
-    """Reference CPU path timed on this box's host cores, on a bounded sample of the same kind
-    of workload: a 64^3 tunnel with a ball obstacle at the workload's iteration count, stepped
-    until ~budget_s seconds have passed.  Uses the compiled reference (oracle/_ref/libref.so,
-    "reference") when it travelled with the repo, else the C restatement ("port")."""
+def cpu_baseline(budget_s=10.0):
+    """The reference CPU path timed on this box's host cores, on the two quoted configurations a CPU can
+    finish (the GPU workload itself, 512^3 / 80 iterations, is ~10 minutes per step on 16 cores):
+      * BASELINE config 1 exactly -- 64^3 empty tunnel, 50 steps, 20 iterations, constructor defaults --
+        on all granted cores, and (bounded to `budget_s`) on one thread, the reference's only deterministic
+        configuration (SURVEY F1);
+      * BASELINE config 2's grid -- 256^3, ball obstacle, 40 iterations -- ONE step on all granted cores:
+        the sample `value` is quoted on, next to which the line's `extra_256` is the GPU on the same config.
+    Uses the compiled reference (oracle/_ref/libref.so, kind "reference") when it travelled with the
+    repo, else the C restatement (kind "port")."""
     import numpy as np
     from oracle import cpu_ref as O
     O.build()
-    W = H = D = 64
     # the box's CPU share for one GPU is 16 cores even where os.cpu_count() reports the whole host
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("FS_CPU_BASELINE_THREADS", "16"))))
-    z, y, x = np.mgrid[0:D + 2, 0:H + 2, 0:W + 2]
-    mask = ((x - 16) ** 2 + (y - 32) ** 2 + (z - 32) ** 2) <= 64
-    if O.have_reference():
-        kind, sim = "reference", O.Reference(W, H, D, threads=cores, iter=1, acc=acc)
-    else:
-        kind, sim = "port", O.Oracle(W, H, D, solver=O.GS_LEX, threads=cores, iter=1, acc=acc)
-    sim.set_mask(mask)
+    kind = "reference" if O.have_reference() else "port"
 
-    def timed(budget):
-        sim.run_one()                   # warm caches / thread pool
+    def make(W, H, D, threads, acc):
+        if kind == "reference":
+            return O.Reference(W, H, D, threads=threads, iter=1, acc=acc)
+        return O.Oracle(W, H, D, solver=O.GS_LEX, threads=threads, iter=1, acc=acc)
+
+    def run_steps(sim, nmax, budget):
         n, t0 = 0, time.perf_counter()
-        while True:
+        while n < nmax:
             sim.run_one()
             n += 1
-            el = time.perf_counter() - t0
-            if el >= budget or n >= 200:
-                return n, el
+            if time.perf_counter() - t0 >= budget:
+                break
+        return n, time.perf_counter() - t0
 
-    n, el = timed(budget_s)
+    # config 1, all cores: the full 50 steps (a few seconds)
+    sim = make(64, 64, 64, cores, 20)
+    n_all, el_all = run_steps(sim, 50, 120.0)
+    sim.close()
+    # config 1, one thread: as many of the 50 steps as fit the budget
+    sim = make(64, 64, 64, 1, 20)
+    n_one, el_one = run_steps(sim, 50, budget_s)
+    sim.close()
+    c1 = 64 ** 3
     out = {
-        "value": W * H * D * n / el, "unit": "cells*steps/s", "cores": cores, "kind": kind,
-        "sample": "64x64x64 tunnel, ball obstacle r=8, acc=%d, %d steps in %.1f s, OpenMP %d threads, dumps off"
-                  % (acc, n, el, cores),
+        "config1": {"workload": "64x64x64 empty tunnel, 20 iterations (BASELINE config 1)",
+                    "cells_steps_per_sec": c1 * n_all / el_all, "steps": n_all, "seconds": el_all, "threads": cores,
+                    "cells_steps_per_sec_1_thread": c1 * n_one / el_one, "steps_1_thread": n_one, "seconds_1_thread": el_one},
+        "cores": cores, "kind": kind, "unit": "cells*steps/s",
         "cpu_model": cpu_model(), "host_cpus_visible": os.cpu_count(),
     }
-    # the deterministic configuration of the reference (SURVEY F1), for orientation
-    sim.threads = 1
-    n1, el1 = timed(min(budget_s, 5.0))
-    out["value_1_thread"] = W * H * D * n1 / el1
+    if budget_s >= 5.0:
+        # config 2's grid, one step (10-30 s of CPU work on 16 cores)
+        W = H = D = 256
+        z, y, x = np.mgrid[0:D + 2, 0:H + 2, 0:W + 2]
+        mask = ((x - 64) ** 2 + (y - 128) ** 2 + (z - 128) ** 2) <= 38 ** 2
+        del z, y, x
+        sim = make(W, H, D, cores, 40)
+        sim.set_mask(mask)
+        del mask
+        n2, el2 = run_steps(sim, 1, 0.0)
+        sim.close()
+        out["value"] = W * H * D * n2 / el2
+        out["sample"] = ("256x256x256 tunnel, ball obstacle r=38, 40 iterations (BASELINE config 2's grid), 1 step in "
+                         "%.1f s, OpenMP %d threads, dumps off; config1 = 64x64x64 empty, 20 iterations, %d steps in %.1f s"
+                         % (el2, cores, n_all, el_all))
+    else:                                                # short form (tests): config 1 only
+        out["value"] = out["config1"]["cells_steps_per_sec"]
+        out["sample"] = "64x64x64 empty tunnel, 20 iterations (BASELINE config 1), %d steps in %.1f s, OpenMP %d threads, dumps off" % (
+            n_all, el_all, cores)
+    out["value_1_thread"] = out["config1"]["cells_steps_per_sec_1_thread"]
     return out
 
 
@@ -152,7 +202,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--cpu-budget", type=float, default=10.0,
+                    help="seconds for the one-thread leg of cpu_baseline; below 5 the 256^3 sample is skipped (tests)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "shm"],
                     help="shm: development rehearsal of the N>1 path on fewer GPUs than ranks (host-staged "
                          "halo planes through shared memory, torch.distributed over gloo); never a result")
@@ -252,14 +303,26 @@ def main():
             dist.destroy_process_group()
         return
 
-    traffic = None
+    # roofline.traffic: HBM bytes per launch of the dominant kernel from the committed PMC passes -- only when
+    # they were taken on THIS code and THIS launch plan (profiles/sweep_traffic.json carries a stamp: hash of
+    # the kernel sources, grid, workgroup shape and z-chunk plan); anything else prints null, never a stale number
+    traffic, traffic_note = None, "no PMC measurement committed for this workload/kernel"
+    triple_plan = sim._geti("triple_plan")
     tpath = os.path.join(ROOT, "profiles", "sweep_traffic.json")
     if os.path.exists(tpath) and args.precision == "fp32":
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get(name, {}).get(kernel, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+                entry = json.load(f).get(name, {}).get(kernel, {})
+            stamp = entry.get("stamp") or {}
+            want = {"kernels_sha": kernels_sha(), "grid": [W, H, D], "pair_shape": pair_shape, "triple_plan": triple_plan}
+            if entry and all(stamp.get(k) == v for k, v in want.items()):
+                traffic = entry.get("hbm_bytes_per_launch")
+                traffic_note = "rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, KiB units), measured at commit %s" % stamp.get("commit", "?")
+            elif entry:
+                traffic_note = "committed PMC measurement is for another build or launch plan (stamp %s, this run %s)" % (
+                    json.dumps(stamp, sort_keys=True), json.dumps(want, sort_keys=True))
+        except Exception as e:  # noqa: BLE001
+            traffic_note = "could not read profiles/sweep_traffic.json: %s" % e
 
     out = {
         "metric": "cells_steps_per_sec",
@@ -289,7 +352,7 @@ def main():
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": bytes_per_launch, "solver_iterations_per_launch": iters_per_launch,
             "avg_launch_ms": avg_ms, "launches": k_n, "workgroup_shape_id": pair_shape,
-            "launch_plan_three_sweeps": sim._geti("triple_plan"),
+            "launch_plan_three_sweeps": triple_plan, "traffic_note": traffic_note,
             "note": "achieved = 12 B x cells x iterations per launch / HIP-event launch time; above the "
                     "physical HBM rate when several iterations share one pass over memory (temporal blocking); "
                     "traffic = measured HBM bytes per launch (rocprofv3 PMC, profiles/)",
@@ -334,6 +397,26 @@ def main():
             "jacobi_iter_per_sec": it2,
             "sweep_GBps_algorithmic": 12 * 256 ** 3 * it2 / 1e9,
         }
+        # Equal-quality view of the headline (the solver here is Jacobi, the reference sweeps in place, i.e.
+        # Gauss-Seidel at one thread): residual of the pressure equation of this developed flow after the same
+        # number of iterations in both orders, and after twice as many Jacobi iterations.
+        import numpy as np
+        div2, obs2 = s2.get(F.DIVERGENCE), s2.get(F.OBS)
+        q = {}
+        for label, solver, n in (("jacobi_%d" % c2["acc"], "jacobi", c2["acc"]), ("jacobi_%d" % (2 * c2["acc"]), "jacobi", 2 * c2["acc"]),
+                                 ("reference_order_%d" % c2["acc"], "gs_lex", c2["acc"])):
+            s2.set_option("solver", solver)
+            s2.acc = n
+            s2.set(F.PRESSURE, np.zeros_like(div2))
+            s2.set(F.DIVERGENCE, div2)
+            s2.linear_solver(0, F.PRESSURE, F.DIVERGENCE, 1.0, 6.0)
+            q[label] = pressure_residual(s2.get(F.PRESSURE), div2, obs2)
+        out["solver_quality_256"] = {
+            "relative_residual_after_iterations": q,
+            "note": "pressure equation of the c2 flow after 6 steps, zero initial guess; reference_order = the reference's in-place "
+                    "sweep at one thread (solver=gs_lex); the headline's Jacobi needs about twice the iterations for the same residual",
+        }
+        del div2, obs2
         s2.close()
 
     if world == 1 and not args.no_extra and name == "c3":
@@ -388,7 +471,7 @@ def main():
         s5.close()
 
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(acc, budget_s=args.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -463,9 +463,13 @@ struct Engine : EngineBase {
         pair_shape = 0;
         int tmp = acquire(src, rhs);
         if (tmp < 0) return fail(FS_ENOMEM, "array pool exhausted");
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
+        struct Release {                                   // error paths must not leak the scratch array or the events
+            bool* held; int id; hipEvent_t e0 = nullptr, e1 = nullptr;
+            ~Release() { held[id] = false; if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+        } rel{held, tmp};
+        HIP_TRY(hipEventCreate(&rel.e0));
+        HIP_TRY(hipEventCreate(&rel.e1));
+        hipEvent_t e0 = rel.e0, e1 = rel.e1;
         float best = 1e30f;
         for (int shape = 0; shape < n; ++shape)
             for (int alt = 0; alt < 3; ++alt) {          // candidate id = shape + 8 * (rank of the chunk count)
@@ -500,9 +504,6 @@ struct Engine : EngineBase {
                 }
             if (S->tune.fuse >= 4 || best3 / 3.0f < best / 2.0f) triple_alt = alt3;   // fuse 4: force (tests, tuning)
         }
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
-        held[tmp] = false;
         return FS_OK;
     }
 

@@ -2,7 +2,7 @@
 # Regenerates the evidence set under profiles/ for one round tag.  Run ON THE GPU BOX through gpurun:
 #   gpurun --timeout 1200 -- 'tools/make_profiles.sh r02a'
 # and then, back in the container, copy what it left in gpurun_out/profiles_<tag>/ into profiles/ and run
-#   python3 tools/pmc_to_traffic.py gpurun_out/profiles_<tag>/pmc_fetch gpurun_out/profiles_<tag>/pmc_write c3
+#   python3 tools/pmc_to_traffic.py gpurun_out/profiles_<tag>/pmc_fetch gpurun_out/profiles_<tag>/pmc_write c3 gpurun_out/profiles_<tag>/pmc_fetch_bench.json
 # (rewrites profiles/sweep_traffic.json, which bench.py reads for roofline.traffic).
 #
 # Rules of the pool this script respects: the profiled program follows `--` directly (python3, no env /
@@ -20,7 +20,7 @@ timeout -k 10 400 python3 bench.py > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kernel_stats --output-format csv -- $B --steps 5 --warmup 2 \
     > $OUT/bench_c3_under_rocprofv3.json 2> $OUT/rocprof.err
 # 3. HBM traffic: two PMC passes
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_f.err
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- $B --steps 2 --warmup 1 > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_f.err
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write --output-format csv -- $B --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_w.err
 # 4. issue-side counters of the solver kernels (VALU share, waits)
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE \

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE output directories into per-launch HBM bytes of
-the solver kernels (development tool):  python tools/pmc_to_traffic.py <fetch_dir> <write_dir> <workload>
+the solver kernels (development tool):
+    python tools/pmc_to_traffic.py <fetch_dir> <write_dir> <workload> [<bench line of the same build>.json]
+Each entry is stamped with the hash of the kernel sources, the grid and -- from the bench line -- the launch
+plan it was measured on; bench.py prints roofline.traffic only for a run that matches the stamp.
 
 gfx950 corrections (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): FETCH_SIZE and
 WRITE_SIZE are in units of 1024 B; FETCH_SIZE reports exactly half of the bytes of a wide
@@ -14,6 +17,20 @@ import sys
 
 fetch_dir, write_dir, workload = sys.argv[1:4]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import subprocess  # noqa: E402
+
+from bench import WORKLOADS, kernels_sha  # noqa: E402
+
+stamp = {"kernels_sha": kernels_sha(), "grid": [WORKLOADS[workload][k] for k in ("W", "H", "D")]}
+try:
+    stamp["commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:  # noqa: BLE001
+    stamp["commit"] = "unknown"
+if len(sys.argv) > 4:
+    line = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+    stamp["pair_shape"] = line["roofline"]["workgroup_shape_id"]
+    stamp["triple_plan"] = line["roofline"]["launch_plan_three_sweeps"]
 KEYS = ("jacobi_triple_kernel", "jacobi_pair_kernel", "jacobi_sweep_kernel", "advect_velocity_kernel", "advect_kernel", "divergence_march_kernel",
         "gradient_march_kernel", "divergence_kernel", "gradient_kernel")
 
@@ -40,6 +57,7 @@ for k in sorted(set(f) | set(w)):
     data[workload][k] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
                          "FETCH_SIZE_raw_mean": f.get(k), "WRITE_SIZE_raw_mean": w.get(k),
                          "dispatches_sampled": [nf.get(k, 0), nw.get(k, 0)],
-                         "correction": "read = 2 * FETCH_SIZE * 1024 (gfx950 half-count), write = WRITE_SIZE * 1024"}
+                         "correction": "read = 2 * FETCH_SIZE * 1024 (gfx950 half-count), write = WRITE_SIZE * 1024",
+                         "stamp": stamp}
     print(k, "read %.1f MB write %.1f MB" % (rd / 1e6, wr / 1e6))
 json.dump(data, open(out_path, "w"), indent=1)
