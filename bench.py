@@ -274,8 +274,8 @@ def main():
         elapsed = fsdist.max_over_ranks(dist, elapsed, device=ctl_device)
 
     # dominant kernel: the solver sweep, HIP events on the solver's own stream over the timed
-    # region.  Single GPU runs it as jacobi_pair_kernel (two iterations per launch, temporal
-    # blocking); z-slab ranks as jacobi_sweep_kernel (one iteration per launch).
+    # region (csrc/sweep_fused.hip: three iterations per launch for fp32 rows up to 512 cells, two for
+    # fp64 and for rows of 1024 cells; temporal blocking).
     fams = ("sweep", "sweep_pair", "sweep_triple", "divergence", "gradient", "advect", "misc", "comm")
     fam = {k: sim.timing(k) for k in fams}
     local_cells = W * H * sim.local_depth
@@ -286,10 +286,11 @@ def main():
     tri_ms, tri_n = fam["sweep_triple"]
     # the dominant kernel is whichever solver kernel the time went to: three sweeps per launch where the
     # host driver found that faster on this grid, else two (z-slab ranks: always two), else one
+    two_name = "jacobi_fused_kernel<NL=2>" if sim._geti("two_sweep_fused") else "jacobi_pair_kernel"
     if tri_ms >= pair_ms and tri_n > 0:
-        kernel, iters_per_launch, k_ms, k_n = "jacobi_triple_kernel", 3, tri_ms, tri_n
+        kernel, iters_per_launch, k_ms, k_n = "jacobi_fused_kernel<NL=3>", 3, tri_ms, tri_n
     elif pair_n > 0:
-        kernel, iters_per_launch, k_ms, k_n = "jacobi_pair_kernel", 2, pair_ms, pair_n
+        kernel, iters_per_launch, k_ms, k_n = two_name, 2, pair_ms, pair_n
     else:
         kernel, iters_per_launch, k_ms, k_n = "jacobi_sweep_kernel", 1, one_ms, one_n
     bytes_per_launch = SWEEP_BYTES_PER_CELL * (elem // 4) * local_cells * iters_per_launch
@@ -352,7 +353,7 @@ def main():
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": bytes_per_launch, "solver_iterations_per_launch": iters_per_launch,
             "avg_launch_ms": avg_ms, "launches": k_n, "workgroup_shape_id": pair_shape,
-            "launch_plan_three_sweeps": triple_plan, "traffic_note": traffic_note,
+            "launch_plan_three_sweeps": triple_plan, "two_sweep_kernel": two_name, "traffic_note": traffic_note,
             "note": "achieved = 12 B x cells x iterations per launch / HIP-event launch time; above the "
                     "physical HBM rate when several iterations share one pass over memory (temporal blocking); "
                     "traffic = measured HBM bytes per launch (rocprofv3 PMC, profiles/)",

@@ -102,7 +102,7 @@ struct ShmTransport {
         std::atomic<int> count;
         std::atomic<int> generation;
         std::atomic<int> ready;        // set by rank 0 once the segment is sized
-        size_t slot_bytes;             // capacity of one mailbox slot / one gathered plane
+        size_t slot_bytes;             // capacity of one mailbox slot (four fp64 planes); a gathered plane takes a quarter
         int gather_planes;
     };
     std::string name;
@@ -114,7 +114,7 @@ struct ShmTransport {
 
     static size_t layout(size_t slot, int nranks, int gplanes) { return 4096 + slot * ((size_t)2 * nranks + gplanes) + 4096; }
     char* mailbox(int r, int side) { return base + 4096 + hdr->slot_bytes * ((size_t)2 * r + side); }
-    char* gather(int plane) { return base + 4096 + hdr->slot_bytes * ((size_t)2 * nranks) + (hdr->slot_bytes / 2) * (size_t)plane; }
+    char* gather(int plane) { return base + 4096 + hdr->slot_bytes * ((size_t)2 * nranks) + (hdr->slot_bytes / 4) * (size_t)plane; }
     double* stats(int r) { return reinterpret_cast<double*>(base + 4096 + hdr->slot_bytes * ((size_t)2 * nranks + hdr->gather_planes)) + 4 * r; }   // gather area over-reserved
 
     // every rank calls this with the same sizes before the first exchange
@@ -253,7 +253,7 @@ struct Comm {
     int shm_ready(const GridDesc& g, int Dglobal)
     {
         // slots sized for fp64 planes so that one segment serves every field type
-        return shm->ensure((size_t)g.sz * 8 * 2, Dglobal + 2, &err);   // a mailbox slot holds two planes
+        return shm->ensure((size_t)g.sz * 8 * 4, Dglobal + 2, &err);   // a mailbox slot holds up to four planes
     }
 
     // Refresh the `depth` halo planes on each slab side of `a` (shifted pointer: plane z starts at
@@ -270,7 +270,7 @@ struct Comm {
         char* send_hi = base + plane * (size_t)(g.D - depth + 1);       // planes D-depth+1 .. D
         char* recv_hi = base + plane * (size_t)(g.D + 1);               // planes D+1 .. D+depth
         if (shm) {
-            if (depth > 2) { err = "shm transport carries at most two planes"; return -1; }
+            if (depth > 4) { err = "shm transport carries at most four planes"; return -1; }
             if (shm_ready(g, Dglobal)) return -1;
             FS_HIPC(hipStreamSynchronize(st));
             if (rank > 0) FS_HIPC(hipMemcpyAsync(shm->mailbox(rank - 1, 1), send_lo, bytes, hipMemcpyDeviceToHost, st));

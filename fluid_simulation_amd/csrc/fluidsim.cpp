@@ -79,6 +79,7 @@ struct EngineBase {
     virtual int apply_solid_cells(const int* cells, long n) = 0;
     virtual int tuned_shape() const = 0;
     virtual int tuned_triple() const = 0;
+    virtual int halo_depth() const = 0;
     virtual int streamlines(int density, double proximity, int max_length, double step_size, double threshold) = 0;
 };
 
@@ -188,9 +189,10 @@ struct Engine : EngineBase {
     T* gathered = nullptr;              // gathered advection source (z-slabs only), LEAD-shifted global array
     T* gathered3[3] = {nullptr, nullptr, nullptr};   // the same for the three sources of the fused velocity advection
     double* red = nullptr;              // stats scratch
-    int pair_shape = -1;                // fastest pair-kernel workgroup shape for this grid (timed once)
-    int tuned_fuse = -1;                // value of the sweep_fuse option the two choices below were timed under
-    int triple_alt = -1;                // >= 0: three sweeps per pass beat the pair kernel on this grid (launch plan id)
+    static constexpr int FUSED2 = 64;   // pair_shape >= FUSED2: the two-sweep passes run jacobi_fused_kernel<NL = 2>, plan id - FUSED2
+    int pair_shape = -1;                // fastest two-sweep launch plan for this grid (timed once)
+    int tuned_fuse = -1, tuned_pair_shape_opt = -1;   // option values the two choices here were timed under
+    int triple_alt = -1;                // >= 0: three sweeps per pass beat two on this grid (launch plan id)
     hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
     hipEvent_t ev_edges = nullptr, ev_halo = nullptr;
     static constexpr int NRED = 3 * 1024 + 3;
@@ -217,7 +219,9 @@ struct Engine : EngineBase {
         g.D = cm.active() ? cm.local_depth(S->D) : S->D;
         g.sy = ((long)(g.W + 5) + 3) / 4 * 4;
         g.sz = g.sy * (g.H + 2);
-        g.zh = cm.active() ? 2 : 1;    // z-slabs keep two halo planes per side (pair kernel across slab boundaries)
+        // z-slabs keep as many halo planes per side as the deepest fused pass has levels (it recomputes the lower
+        // levels of the neighbours' boundary planes): three where the three-sweep kernel exists, else two
+        g.zh = !cm.active() ? 1 : (std::is_same<T, float>::value && g.W <= 512 && g.D >= 3) ? 3 : 2;
         g.lead = fs::LEAD + (long)(g.zh - 1) * g.sz;
         g.n = g.sz * (g.D + 2 * g.zh) + 8;   // lead + tail so that a dwordx4 at the last ghost stays in bounds
         g.n = (g.n + 3) / 4 * 4;
@@ -344,6 +348,35 @@ struct Engine : EngineBase {
     }
 
     // ---- linearSolver (simulation.cpp:251-273) -----------------------------------------
+    // One pass over memory that applies `levels` (1, 2 or 3) Jacobi sweeps to planes zf..zl (and, with
+    // second >= 0, to the equally long range starting there).
+    void launch_pass(hipStream_t st, int levels, bool rb, const T* src_, const T* rhs_, T* dst_, int b, T a, T inv_c, int zf,
+                     int zl, int second = -1)
+    {
+        const T omega = rb ? (T)S->omega : (T)0;
+        if (levels == 3)
+            fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 3, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, triple_alt, second);
+        else if (levels == 2 && !rb && pair_shape >= FUSED2)
+            fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 2, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape - FUSED2, second);
+        else if (levels == 2)
+            fs::launch_jacobi_pair<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape, second, omega);
+        else
+            fs::launch_jacobi<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, second);
+    }
+    bool two_sweep_kernels() const
+    {
+        return fs::pair_supported<T>(S->tune, g, sc) || fs::fused_supported<T>(S->tune, g, sc, 2);
+    }
+    int ensure_tuned(int cur, int rhs, int b, T a, T inv_c)
+    {
+        if (!two_sweep_kernels() && !fs::fused_supported<T>(S->tune, g, sc, 3)) return FS_OK;
+        const int opt = S->tune.pair_shape + 16 * S->tune.two_kind;
+        if (pair_shape >= 0 && tuned_fuse == S->tune.fuse && tuned_pair_shape_opt == opt) return FS_OK;
+        tuned_fuse = S->tune.fuse;
+        tuned_pair_shape_opt = opt;
+        return choose_pair_shape(cur, rhs, b, a, inv_c);
+    }
+
     // Returns the id of the array holding the result (held); `cur` holds the initial
     // iterate (may equal rhs when the caller aliased a snapshot).
     int solve(int b, int cur, int rhs, T a, T c, int sweeps, int* result)
@@ -360,107 +393,97 @@ struct Engine : EngineBase {
         }
         int src = cur;
         bool src_temp = false;
-        const bool pairs = fs::pair_supported<T>(S->tune, g, sc);
         // solver=rbsor: every iteration is one pass of the pair kernel (its two levels are the two colours)
         const bool rb = (S->solver == FS_SOLVER_RBSOR);
-        if (rb && !pairs) return fail(FS_EINVAL, "solver=rbsor needs rows of at most 1024 cells and sweep_fuse >= 2");
-        const T omega = rb ? (T)S->omega : (T)0;
-        int pair_span = -1, span_fam = FAM_PAIR;
-        long pair_launches = 0;
-        if (pairs && (pair_shape < 0 || tuned_fuse != S->tune.fuse)) {
-            tuned_fuse = S->tune.fuse;
-            int rc = choose_pair_shape(cur, rhs, b, a, inv_c);
+        if (rb && !fs::pair_supported<T>(S->tune, g, sc))
+            return fail(FS_EINVAL, "solver=rbsor needs rows of at most 1024 cells and sweep_fuse >= 2");
+        {
+            int rc = ensure_tuned(cur, rhs, b, a, inv_c);
             if (rc) return rc;
         }
-        if (pairs && S->comm.active()) {
-            // the pair kernel recomputes level 1 of the neighbours' boundary planes: it reads the
-            // right-hand side there, so its first halo plane must be current
+        // The passes of this solve: three sweeps per pass while at least three remain (where that kernel
+        // exists and was found faster), then two, then one.  Under z-slabs every rank derives the same list
+        // (it fixes the depth of every halo exchange).
+        const bool can2 = two_sweep_kernels(), can3 = triple_alt >= 0;
+        std::vector<int> plan;
+        for (int left = sweeps; left > 0;) {
+            if (rb) { plan.push_back(2); left -= 1; continue; }          // an rbsor iteration runs as a two-level pass
+            const int lv = (can3 && left >= 3) ? 3 : (can2 && left >= 2) ? 2 : 1;
+            plan.push_back(lv);
+            left -= lv;
+        }
+        const int npass = (int)plan.size();
+        if (npass > 0 && S->comm.active() && (plan[0] > 1 || npass > 1)) {
+            // a fused pass recomputes the lower levels of the neighbours' boundary planes: it reads the
+            // right-hand side there, so its halo planes must be current
             int rc = halo(arr[rhs]);
             if (rc) return rc;
         }
-        for (int it = 0; it < sweeps; ++it) {
+        int span = -1, span_fam = -1;
+        long span_launches = 0;
+        auto close_span = [&]() {
+            if (span >= 0) S->span_end(span, span_launches);
+            span = -1;
+            span_launches = 0;
+        };
+        for (int i = 0; i < npass; ++i) {
+            const int lv = plan[i];
             int dst = acquire(src, rhs);
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
-            const bool three = !rb && pairs && triple_alt >= 0 && it + 2 < sweeps;   // three sweeps per pass over memory
-            const bool two = rb || (pairs && !three && it + 1 < sweeps);              // two
-            auto run = [&](hipStream_t st, int zf, int zl, int second = -1) {
-                if (three) launch_triple(arr[src], arr[rhs], arr[dst], b, a, inv_c, triple_alt);
-                else if (two) fs::launch_jacobi_pair<T>(st, S->tune, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, pair_shape, second, omega);
-                else fs::launch_jacobi<T>(st, S->tune, g, sc, arr[src], arr[rhs], arr[dst], kill, b, a, inv_c, zf, zl, second);
-            };
-            const int e = g.zh;                          // planes a neighbour needs from each boundary
-            if (S->comm.active() && S->overlap && g.D >= 2 * e + 8) {
-                // Boundary planes first (both regions in one launch); their exchange then travels on
-                // the high-priority communication stream while the interior planes are computed
-                // (SURVEY 8e).  Running the boundary launch concurrently with the interior one on a
-                // second stream was measured slower: the interior workgroups fill every CU.
-                const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
-                if (pair_span < 0) pair_span = S->span_begin(FAM_PAIR);   // one event pair per solve (exchanges included)
-                pair_launches += two ? 1 : 0;
-                if (!sc.lo_wall && !sc.hi_wall) run(S->stream, 1, e, g.D - e + 1);
-                else if (!sc.lo_wall) run(S->stream, 1, e);
-                else if (!sc.hi_wall) run(S->stream, g.D - e + 1, g.D);
-                HIP_TRY(hipEventRecord(ev_edges, S->stream));
-                run(S->stream, in_lo, in_hi);
-                HIP_TRY(hipStreamWaitEvent(comm_stream, ev_edges, 0));
-                {
-                    int rc = S->comm.exchange_halo(comm_stream, arr[dst], g, sizeof(T), S->D, g.zh);
-                    if (rc) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
-                }
-                HIP_TRY(hipEventRecord(ev_halo, comm_stream));
-                HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
-            } else if (S->comm.active()) {
-                if (pair_span < 0) pair_span = S->span_begin(FAM_PAIR);
-                pair_launches += two ? 1 : 0;
-                run(S->stream, 1, g.D);
-                int rc = S->comm.exchange_halo(S->stream, arr[dst], g, sizeof(T), S->D, g.zh);
-                if (rc) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
+            // one event pair around each run of equal passes (an event pair per launch costs 2 % at 512^3 and
+            // 16 % at 256^3); launches are counted so that time / launches is the mean launch time.  On slabs
+            // the exchanges fall inside the span.
+            const int fam = lv == 3 ? FAM_TRIPLE : lv == 2 ? FAM_PAIR : FAM_SWEEP;
+            if (span >= 0 && fam != span_fam) close_span();
+            if (span < 0) { span = S->span_begin(fam); span_fam = fam; }
+            ++span_launches;
+            if (!S->comm.active()) {
+                launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, g.D);
             } else {
-                // single GPU: one event pair around the whole run of pair launches of this solve (an
-                // event pair per launch costs 2 % at 512^3 and 16 % at 256^3), one around a trailing
-                // single sweep; launches are counted so that time / launches is the mean launch time
-                const int fam = three ? FAM_TRIPLE : FAM_PAIR;
-                if (pair_span >= 0 && (!(two || three) || fam != span_fam)) {
-                    S->span_end(pair_span, pair_launches);
-                    pair_span = -1;
-                    pair_launches = 0;
-                }
-                if (two || three) {
-                    if (pair_span < 0) { pair_span = S->span_begin(fam); span_fam = fam; }
-                    ++pair_launches;
-                }
-                if (two || three) run(S->stream, 1, g.D);
-                else {
-                    ScopedSpan sp(S, FAM_SWEEP);
-                    run(S->stream, 1, g.D);
+                // planes a neighbour needs of this pass's result: as many as its next pass has levels; after
+                // the last pass the halos are brought to their full depth (what every other kernel assumes)
+                const int e = (i + 1 < npass) ? plan[i + 1] : g.zh;
+                if (S->overlap && g.D >= 2 * e + 8) {
+                    // Boundary planes first (both regions in one launch); their exchange then travels on
+                    // the high-priority communication stream while the interior planes are computed
+                    // (SURVEY 8e).  Running the boundary launch concurrently with the interior one on a
+                    // second stream was measured slower: the interior workgroups fill every CU.
+                    const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
+                    if (!sc.lo_wall && !sc.hi_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e, g.D - e + 1);
+                    else if (!sc.lo_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e);
+                    else if (!sc.hi_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, g.D - e + 1, g.D);
+                    HIP_TRY(hipEventRecord(ev_edges, S->stream));
+                    launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, in_lo, in_hi);
+                    HIP_TRY(hipStreamWaitEvent(comm_stream, ev_edges, 0));
+                    if (S->comm.exchange_halo(comm_stream, arr[dst], g, sizeof(T), S->D, e))
+                        return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
+                    HIP_TRY(hipEventRecord(ev_halo, comm_stream));
+                    HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
+                } else {
+                    launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, g.D);
+                    if (S->comm.exchange_halo(S->stream, arr[dst], g, sizeof(T), S->D, e))
+                        return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
                 }
             }
-            if (two && !rb) ++it;
-            if (three) it += 2;
             if (src_temp) held[src] = false;
             src = dst;
             src_temp = true;
         }
-        if (pair_span >= 0) S->span_end(pair_span, pair_launches);
+        close_span();
         if (!src_temp) held[src] = true;
         *result = src;
         return FS_OK;
     }
 
-    void launch_triple(const T* src_, const T* rhs_, T* dst_, int b, T a, T inv_c, int alt)
-    {
-        if constexpr (std::is_same<T, float>::value)
-            fs::launch_jacobi_triple(S->stream, S->tune, g, src_, rhs_, dst_, kill, b, a, inv_c, alt);
-    }
-
-    // Times the candidate launch plans of the pair kernel on this grid -- workgroup shape x the three
-    // best z-chunk counts of the launcher's model -- two launches each into a scratch array, the second
-    // one timed, and keeps the fastest.  Every shape computes the same
-    // bits, so this only ever changes speed.
+    // Times the candidate launch plans of the two-sweep kernels on this grid -- the pair kernel's workgroup
+    // shapes and the fused kernel's (ids FUSED2 + shape), each x the three best z-chunk counts of the
+    // launcher's model -- two launches each into a scratch array, the second one timed, and keeps the
+    // fastest; then the same for the three-sweep kernel, which is used where a sweep costs less that way.
+    // Every plan computes the same bits, so this only ever changes speed.
     int choose_pair_shape(int src, int rhs, int b, T a, T inv_c)
     {
-        const int n = fs::pair_shape_count<T>(g);
         pair_shape = 0;
+        triple_alt = -1;
         int tmp = acquire(src, rhs);
         if (tmp < 0) return fail(FS_ENOMEM, "array pool exhausted");
         struct Release {                                   // error paths must not leak the scratch array or the events
@@ -470,39 +493,62 @@ struct Engine : EngineBase {
         HIP_TRY(hipEventCreate(&rel.e0));
         HIP_TRY(hipEventCreate(&rel.e1));
         hipEvent_t e0 = rel.e0, e1 = rel.e1;
-        float best = 1e30f;
-        for (int shape = 0; shape < n; ++shape)
-            for (int alt = 0; alt < 3; ++alt) {          // candidate id = shape + 8 * (rank of the chunk count)
-                const int cand = shape + 8 * alt;
-                float ms = 1e30f;
-                for (int rep = 0; rep < 2; ++rep) {
-                    HIP_TRY(hipEventRecord(e0, S->stream));
-                    fs::launch_jacobi_pair<T>(S->stream, S->tune, g, sc, arr[src], arr[rhs], arr[tmp], kill, b, a, inv_c, 1, g.D, cand);
-                    HIP_TRY(hipEventRecord(e1, S->stream));
-                    HIP_TRY(hipEventSynchronize(e1));
-                    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-                }
-                if (ms < best) { best = ms; pair_shape = cand; }
+        auto timed = [&](int levels, int cand, float* ms) -> int {
+            const int keep_pair = pair_shape, keep_triple = triple_alt;
+            if (levels == 3) triple_alt = cand; else pair_shape = cand;
+            int rc = FS_OK;
+            for (int rep = 0; rep < 2 && !rc; ++rep) {
+                if (hipEventRecord(e0, S->stream) != hipSuccess) { rc = fail(FS_EHIP, "hipEventRecord"); break; }
+                launch_pass(S->stream, levels, false, arr[src], arr[rhs], arr[tmp], b, a, inv_c, 1, g.D);
+                if (hipEventRecord(e1, S->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                    hipEventElapsedTime(ms, e0, e1) != hipSuccess)
+                    rc = fail(FS_EHIP, "timing a sweep launch plan failed: %s", hipGetErrorString(hipGetLastError()));
             }
+            pair_shape = keep_pair;
+            triple_alt = keep_triple;
+            return rc;
+        };
+        float best = 1e30f;
+        int best_cand = -1;
+        auto consider2 = [&](int cand) -> int {
+            float ms = 1e30f;
+            int rc = timed(2, cand, &ms);
+            if (rc) return rc;
+            if (ms < best) { best = ms; best_cand = cand; }
+            return FS_OK;
+        };
+        // options: pair_shape > 0 forces a workgroup shape of the pair kernel, two_sweep_kernel one of the two kernels
+        const bool have_fused2 = fs::fused_supported<T>(S->tune, g, sc, 2);
+        const bool forced_pair = S->tune.pair_shape > 0 || S->tune.two_kind == 1 || !have_fused2;
+        const bool forced_fused = !forced_pair && S->tune.two_kind == 2;
+        if (fs::pair_supported<T>(S->tune, g, sc) && !forced_fused)
+            for (int shape = 0; shape < fs::pair_shape_count<T>(g); ++shape)
+                for (int alt = 0; alt < 3; ++alt) {      // candidate id = shape + 8 * (rank of the chunk count)
+                    int rc = consider2(shape + 8 * alt);
+                    if (rc) return rc;
+                }
+        if (have_fused2 && !forced_pair)
+            for (int shape = 0; shape < fs::fused_shape_count<T>(g, 2); ++shape)
+                for (int alt = 0; alt < 3; ++alt) {
+                    int rc = consider2(FUSED2 + shape + 8 * alt);
+                    if (rc) return rc;
+                }
+        if (best_cand >= 0) pair_shape = best_cand;
         // three sweeps per pass, where the kernel exists for this grid: keep it if a sweep costs less
-        triple_alt = -1;
-        if (fs::triple_supported<T>(S->tune, g, sc)) {
+        if (fs::fused_supported<T>(S->tune, g, sc, 3)) {
             float best3 = 1e30f;
             int alt3 = -1;
-            for (int shape = 0; shape < fs::triple_shape_count(g); ++shape)
+            for (int shape = 0; shape < fs::fused_shape_count<T>(g, 3); ++shape)
                 for (int alt = 0; alt < 3; ++alt) {
-                    const int plan = shape + 8 * alt;
+                    const int cand = shape + 8 * alt;
                     float ms = 1e30f;
-                    for (int rep = 0; rep < 2; ++rep) {
-                        HIP_TRY(hipEventRecord(e0, S->stream));
-                        launch_triple(arr[src], arr[rhs], arr[tmp], b, a, inv_c, plan);
-                        HIP_TRY(hipEventRecord(e1, S->stream));
-                        HIP_TRY(hipEventSynchronize(e1));
-                        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-                    }
-                    if (ms < best3) { best3 = ms; alt3 = plan; }
+                    int rc = timed(3, cand, &ms);
+                    if (rc) return rc;
+                    if (ms < best3) { best3 = ms; alt3 = cand; }
                 }
-            if (S->tune.fuse >= 4 || best3 / 3.0f < best / 2.0f) triple_alt = alt3;   // fuse 4: force (tests, tuning)
+            // fuse 4 forces it (tests, tuning); z-slab ranks must all take the same decision (it fixes the
+            // exchange schedule), so there it is not left to each rank's clock
+            if (S->tune.fuse >= 4 || S->comm.active() || best_cand < 0 || best3 / 3.0f < best / 2.0f) triple_alt = alt3;
         }
         return FS_OK;
     }
@@ -817,6 +863,7 @@ struct Engine : EngineBase {
     }
 
     int tuned_shape() const override { return pair_shape; }
+    int halo_depth() const override { return g.zh; }
     int tuned_triple() const override { return triple_alt; }
 
     // ---- the viewer's streamlines (GUI/utils.py:118-213) -------------------------------------
@@ -1046,29 +1093,22 @@ struct Engine : EngineBase {
             bool* held; int a, b; hipEvent_t e0 = nullptr, e1 = nullptr;
             ~Release() { held[a] = held[b] = false; if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
         } rel{held, s1, s2};
-        const bool pairs = fs::pair_supported<T>(S->tune, g, sc);
-        if (pairs && (pair_shape < 0 || tuned_fuse != S->tune.fuse)) {   // same launch plans as solve(); tuned BEFORE the clock starts
-            tuned_fuse = S->tune.fuse;
-            int rc2 = choose_pair_shape(slot[field], slot[prev], b, (T)a, inv_c);
+        {                                                  // same launch plans as solve(); tuned BEFORE the clock starts
+            int rc2 = ensure_tuned(slot[field], slot[prev], b, (T)a, inv_c);
             if (rc2) return rc2;
         }
+        const bool can2 = two_sweep_kernels(), can3 = triple_alt >= 0;
         HIP_TRY(hipEventCreate(&rel.e0));
         HIP_TRY(hipEventCreate(&rel.e1));
         hipEvent_t e0 = rel.e0, e1 = rel.e1;
         // one untimed sweep to fault in code and scratch
-        fs::launch_jacobi<T>(S->stream, S->tune, g, sc, arr[slot[field]], arr[slot[prev]], arr[s1], kill, b, (T)a, inv_c, 1, g.D);
+        launch_pass(S->stream, 1, false, arr[slot[field]], arr[slot[prev]], arr[s1], b, (T)a, inv_c, 1, g.D);
         HIP_TRY(hipEventRecord(e0, S->stream));
         int src = s1, dst = s2;
         for (int r = 0; r < reps; ++r) {
-            if (pairs && triple_alt >= 0 && r + 2 < reps) {
-                launch_triple(arr[src], arr[slot[prev]], arr[dst], b, (T)a, inv_c, triple_alt);
-                r += 2;
-            } else if (pairs && r + 1 < reps) {
-                fs::launch_jacobi_pair<T>(S->stream, S->tune, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D, pair_shape);
-                ++r;
-            } else {
-                fs::launch_jacobi<T>(S->stream, S->tune, g, sc, arr[src], arr[slot[prev]], arr[dst], kill, b, (T)a, inv_c, 1, g.D);
-            }
+            const int lv = (can3 && r + 2 < reps) ? 3 : (can2 && r + 1 < reps) ? 2 : 1;
+            launch_pass(S->stream, lv, false, arr[src], arr[slot[prev]], arr[dst], b, (T)a, inv_c, 1, g.D);
+            r += lv - 1;
             int t = src; src = dst; dst = t;
         }
         HIP_TRY(hipEventRecord(e1, S->stream));
@@ -1221,6 +1261,11 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         s->tune.pair_zc = atoi(value);
     } else if (k == "pair_shape") {
         s->tune.pair_shape = atoi(value);
+    } else if (k == "two_sweep_kernel") {
+        if (v == "auto") s->tune.two_kind = 0;
+        else if (v == "pair") s->tune.two_kind = 1;
+        else if (v == "fused") s->tune.two_kind = 2;
+        else return fail(FS_EINVAL, "two_sweep_kernel: auto | pair | fused");
     } else {
         return fail(FS_EINVAL, "unknown option '%s'", key);
     }
@@ -1238,6 +1283,8 @@ int fs_get_int(fs_sim* s, const char* name, int* out)
     else if (n == "last_advect_reach") *out = s->last_reach;
     else if (n == "pair_shape") *out = s->eng ? s->eng->tuned_shape() : -1;
     else if (n == "triple_plan") *out = s->eng ? s->eng->tuned_triple() : -1;
+    else if (n == "two_sweep_fused") *out = (s->eng && s->eng->tuned_shape() >= 64) ? 1 : 0;   // 1: jacobi_fused_kernel<NL=2>, 0: jacobi_pair_kernel
+    else if (n == "halo_depth") *out = s->eng ? s->eng->halo_depth() : 0;
     else return fail(FS_EINVAL, "unknown int member '%s'", name);
     return FS_OK;
 }

@@ -16,8 +16,8 @@ struct GridDesc {
     long sy, sz;   // row and plane pitch in elements
     long n;        // elements per allocation (including `lead` and the tail pad)
     long lead;     // elements between the allocation base and p: LEAD + (zh-1) planes
-    int zh;        // halo planes kept on each z side: 1 (single GPU) or 2 (z-slabs: planes -1..D+2
-                   // exist so that two fused sweeps can cross a slab boundary)
+    int zh;        // halo planes kept on each z side: 1 (single GPU), 2 or 3 (z-slabs: planes 1-zh..D+zh
+                   // exist so that two / three fused sweeps can cross a slab boundary)
 };
 constexpr int LEAD = 3;
 
@@ -45,11 +45,12 @@ struct SweepTune {
     int zc_len = 0;           // planes per z chunk; 0 = derive from target_blocks
     int target_blocks = 2048; // aim for about this many workgroups per launch
     int abl = 0;
-    int fuse = 3;             // sweeps fused per pass over memory: 1 never, 2 pair kernel only, 3 (default) also time the
+    int fuse = 3;             // sweeps fused per pass over memory: 1 never, 2 two-sweep kernels only, 3 (default) also time the
                               // three-sweep kernel per grid and use it where a sweep costs less, 4 use it wherever it exists
     int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic
     int project_cell = 0;     // 1 = per-cell divergence/gradient kernels instead of the z-marching ones
     int pair_shape = 0;       // >0 forces a pair-kernel workgroup shape (1 = 8, 2 = 10, 3 = 16 waves); 0 = timed choice
+    int two_kind = 0;         // which two-sweep kernel: 0 = timed choice, 1 = jacobi_pair_kernel only, 2 = jacobi_fused_kernel<NL=2> only
 };
 
 // NOTE: the sweep launchers take the KILL-byte array (launch_build_kill), not the flag bytes.
@@ -68,13 +69,18 @@ template <class T>
 void launch_jacobi_pair(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
                         T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
                         int second_first = -1, T omega = (T)0);   // omega != 0: one red-black SOR iteration instead
-// three sweeps per pass (fp32, whole domain on one GPU, W <= 512); `alt` picks among the launcher's
-// three best z-chunk counts like the pair launcher's candidate id >> 3
+// NL = `levels` (2 or 3) sweeps per pass, register-centred (sweep_fused.hip): fp32 x 3 for rows up to 512
+// cells, fp32 x 2 for rows of 513..1024 cells, fp64 x 2 for rows up to 512 cells.  On a z-slab `src` needs
+// `levels` current halo planes per side, `rhs` and `flags` levels-1.  plan = workgroup shape
+// (0 .. fused_shape_count-1) + 8 * (which of the launcher's three best z-chunk counts); second_first as above.
 template <class T>
-bool triple_supported(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc);
-void launch_jacobi_triple(hipStream_t st, const SweepTune& tune, const GridDesc& g, const float* src, const float* rhs,
-                          float* dst, const uint8_t* flags, int b, float a, float inv_c, int plan);
-int triple_shape_count(const GridDesc& g);   // plan = shape (0 .. count-1) + 8 * alt (0..2)
+bool fused_supported(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int levels);
+template <class T>
+int fused_shape_count(const GridDesc& g, int levels);
+template <class T>
+void launch_jacobi_fused(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int levels, const T* src,
+                         const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int plan,
+                         int second_first = -1);
 // number of workgroup shapes (0 .. count-1) worth timing for this grid; results do not depend on the shape
 template <class T>
 int pair_shape_count(const GridDesc& g);

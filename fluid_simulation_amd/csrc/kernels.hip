@@ -10,27 +10,9 @@
 // reference's `c++ -O2` build for the same iteration order.
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#include "kernels_dev.h"
 
 namespace fs {
-
-template <class T>
-struct alignas(16) V4 {
-    T e[4];
-};
-
-__device__ __forceinline__ long cell(const GridDesc& g, int x, int y, int z)
-{
-    return (long)x + (long)y * g.sy + (long)z * g.sz;
-}
-
-// Blocks are dealt round-robin over the 8 XCDs (block b lands on XCD b % 8, each with its
-// own 4 MiB L2).  Remap so that every XCD owns one contiguous range of work items and
-// y-adjacent tiles, which share halo rows, hit the same L2.  Affects speed only.
-__device__ __forceinline__ int xcd_contiguous(int b, int nblk)
-{
-    int q = nblk >> 3, r = nblk & 7, k = b & 7;
-    return k * q + (k < r ? k : r) + (b >> 3);
-}
 
 // =====================================================================================
 // Jacobi sweep with fused setBounds.
@@ -623,424 +605,6 @@ void launch_jacobi_pair<double>(hipStream_t st, const SweepTune& tune, const Gri
     else if (nxw == 2) launch_pair_v<double, 2, 4>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
     else if (nxw == 3) launch_pair_v<double, 3, 3>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
     else launch_pair_v<double, 4, 2>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
-}
-
-// =====================================================================================
-// Three Jacobi sweeps per pass over memory, bit-identical with three launches of
-// jacobi_sweep_kernel.  fp32, whole domain on one GPU, rows up to 512 cells.
-//
-// Same decomposition as the pair kernel (a workgroup owns the full row width times a band of
-// BY rows and marches along z), but register-centred: a wave keeps its own cells of levels
-// 0, 1 and 2 for three consecutive planes in registers (three slots per level, rotated by
-// unrolling the march three times, so nothing is ever copied), and LDS only carries what a
-// wave needs from its neighbours -- the rows just above and below its patch and the two
-// columns beside it -- in a two-slot ring per level.  In iteration zl a wave computes level 1
-// of plane zl, level 2 of plane zl-1 and level 3 of plane zl-2; level j+1 of plane P reads the
-// level-j tile of plane P that was published one iteration earlier, so one barrier per
-// iteration is enough and two slots per ring suffice.  The right-hand side of a plane is needed
-// in three consecutive iterations; each thread parks its own values in a private LDS ring
-// instead of holding four planes of it in registers.
-//
-// setBounds between the levels, exactly as it would happen in memory: interior cells are zeroed
-// (settle4); the ghost columns x = 0, W+1 and ghost rows y = 0, H+1 of a level are written into
-// the LDS tile from the unzeroed values (simulation.cpp:186-201), the ghost planes z = 0, D+1
-// into the register slot the missing plane would occupy (:208-214).
-// Bands overlap by four rows and z chunks by four planes.
-//
-// Status: the host driver times it against the pair kernel once per grid (option sweep_fuse = 3,
-// the default; 4 forces it, 2 disables it) and uses it where a sweep costs less.  MI355X, fp32:
-// 512^3 0.42 ms per pass = 0.14 ms per sweep (pair kernel 0.167), 256^3 0.053 ms per pass; 12 waves
-// of two rows, 150 VGPRs, no scratch, 1.82 GB of HBM traffic per pass (4.3 TB/s: issue-bound, not
-// memory-bound).  What made the difference is written up in DESIGN.md section 4 (uniform wave index
-// through readfirstlane, scalar plane pointers + opaque 32-bit lane offsets, unpredicated loads).
-// =====================================================================================
-template <int N>
-struct IC {
-    static constexpr int value = N;
-};
-
-template <int NXW, int NYW, int RY, bool ALIGNED>
-__global__ __launch_bounds__(NXW* NYW * 64) void jacobi_triple_kernel(GridDesc g, const float* __restrict__ src,
-                                                                       const float* __restrict__ rhs,
-                                                                       float* __restrict__ dst,
-                                                                       const uint8_t* __restrict__ flags, int b, float a,
-                                                                       float inv_c, int zc_len, int nbands, int nblk)
-{
-    using T = float;
-    constexpr int BY = NYW * RY, TW = NXW * 256 + 8, RW = NXW * 256;
-    __shared__ T ring[2][2][BY][TW];                     // [level-1][plane & 1][tile row][x + 3]
-    __shared__ T rsave[3][BY - 2][RW];                   // thread-private: rhs of the last three planes
-
-    const int v = xcd_contiguous(blockIdx.x, nblk);
-    const int band = v % nbands, zc = v / nbands;
-    // readfirstlane: the wave index is the same in all 64 lanes, but only this tells the compiler so -- rows,
-    // row pointers and every row test then live in scalar registers and branch as scalars
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int wx = wave % NXW, wy = wave / NXW;
-    const int W = g.W, H = g.H, D = g.D;
-    const int s = band * (BY - 4);                       // tile row t <-> grid row s + t
-    const int ty0 = wy * RY, y0 = s + ty0;
-    const int xl = wx * 256 + lane * 4;
-    const int x0 = 1 + xl;
-    const bool lane_on = ALIGNED || (x0 <= W);
-    const bool full_group = ALIGNED || (x0 + 3 <= W);
-    const int zbeg = 1 + zc * zc_len, zend = min(D, zbeg + zc_len - 1);   // level-3 output planes
-    if (zbeg > zend) return;                             // block-uniform
-    const int lo1 = max(1, zbeg - 2), hi1 = min(D, zend + 2);             // level-1 planes
-    const int lo2 = max(1, zbeg - 1), hi2 = min(D, zend + 1);             // level-2 planes
-    // rows a level can be computed for: one fewer per level at a band edge, none lost at a wall
-    const bool top_in_tile = (s + BY - 1 >= H + 1);
-    const int r2lo = (s == 0) ? 1 : s + 1, r2hi = top_in_tile ? H : s + BY - 2;
-    const int r3lo = (s == 0) ? 1 : s + 2, r3hi = top_in_tile ? H : s + BY - 3;
-    const int kill_shift = (b == 0) ? 0 : 4;
-    const T zero = 0.0f;
-
-    // Addressing: a plane pointer (wave-uniform, advanced by the march) plus a 32-bit byte offset per
-    // row that never changes.  Loads are never predicated (a predicated load merges with a default
-    // value, which makes the compiler wait for it on the spot instead of one iteration later): rows
-    // outside the array are clamped to a row inside it and lanes beyond the row end read the row
-    // start; what they fetch is never used for a cell that exists.
-    // Per-row byte offsets inside a plane sit in vector registers (there is room: 150 of 168), the plane
-    // pointers in scalar ones -- the scalar file is the scarce one here (100 of 102 in use, and every
-    // spilled scalar costs a v_readlane plus hazard nops on its way back).
-    const unsigned col0 = lane_on ? (unsigned)x0 : 1u;
-    auto clampy = [&](int y) { return (unsigned)min(max(y, 0), H + 1); };
-    unsigned oc[RY];                                     // bytes into a plane of T; kill byte index = (oc + 12) >> 4
-#pragma unroll
-    for (int r = 0; r < RY; ++r) oc[r] = (col0 + clampy(y0 + r) * (unsigned)g.sy) * 4u;
-    const long plane_b = (long)g.sz * 4, plane_f = (long)(g.sz >> 2), row_b = (long)g.sy * 4;
-    // rows below / above the patch: the first / last own row's offset with a wave-uniform step (0 where clamped)
-    const long step_b = (long)(clampy(y0) - clampy(y0 - 1)) * row_b, step_t = (long)(clampy(y0 + RY) - clampy(y0 + RY - 1)) * row_b;
-    auto plane_of = [&](const T* base, int z) { return reinterpret_cast<const char*>(base) + (long)z * plane_b; };   // wave-uniform
-    auto ld4 = [&](const char* ptr, T (&out)[4]) {
-        V4<T> q = *reinterpret_cast<const V4<T>*>(ptr);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = q.e[e];
-    };
-
-    T L0[3][RY][4], L1[3][RY][4] = {}, L2[3][RY][4] = {};
-    T hb[4], ht[4], eL[RY], eR[RY], rcur[RY][4];
-    T gz1[RY][4] = {}, gz2[RY][4] = {};                 // ghost plane D+1 of levels 1 and 2 while it waits for its register slot
-    unsigned flc[RY], kl[3][RY] = {};                    // (not in idle load registers: a select on those would wait for the loads)
-
-    auto load_core = [&](int z, T (&out)[RY][4]) {
-        const char* sp = plane_of(src, z);
-#pragma unroll
-        for (int r = 0; r < RY; ++r) ld4(sp + oc[r], out[r]);
-    };
-    auto load_side = [&](int z) {                        // what level 1 of plane z needs beside the wave's own cells
-        const char* sp = plane_of(src, z);
-        const char* rp = plane_of(rhs, z);
-        const uint8_t* fp = flags + (long)z * plane_f;
-        ld4(sp - step_b + oc[0], hb);
-        ld4(sp + step_t + oc[RY - 1], ht);
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            eL[r] = *reinterpret_cast<const T*>(sp + oc[r] - 4);         // every lane fetches its own x neighbours:
-            eR[r] = *reinterpret_cast<const T*>(sp + oc[r] + 16);        // no shuffles, no edge lanes
-            ld4(rp + oc[r], rcur[r]);
-            flc[r] = (unsigned)fp[(oc[r] + 12u) >> 4];
-        }
-    };
-
-    // one stencil application; simulation.cpp:264-269 order x+1, x-1, y+1, y-1, z+1, z-1
-    auto relax4 = [&](const T (&cc)[4], T left, T right, const T (&ym)[4], const T (&yp)[4], const T (&zm)[4],
-                      const T (&zp)[4], const T (&rh)[4], T (&u)[4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            T xp1 = (e < 3) ? cc[e + 1] : right;
-            T xm1 = (e > 0) ? cc[e - 1] : left;
-            T nb = xp1 + xm1 + yp[e] + ym[e] + zp[e] + zm[e];
-            u[e] = (rh[e] + a * nb) * inv_c;
-        }
-    };
-    // what setBounds leaves in memory for the lane's four cells of an interior row.  Most waves
-    // have no solid cell anywhere near: they skip the zeroing logic on one wave-uniform test.
-    auto settle4 = [&](const T (&u)[4], unsigned fl, T (&st)[4]) {
-        const unsigned kb = (fl >> kill_shift) & 15u;
-        if (ALIGNED && __builtin_amdgcn_ballot_w64(kb != 0) == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st[e] = u[e];
-            return;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool kill = ((kb >> e) & 1u) != 0;
-            if (ALIGNED) st[e] = kill ? zero : u[e];
-            else {
-                const int x = x0 + e;
-                T ghost_src = (e > 0) ? u[e - 1] : zero;
-                st[e] = (x <= W) ? (kill ? zero : u[e]) : ((x == W + 1) ? ghost_src : zero);
-            }
-        }
-    };
-    auto lds_get = [&](const T* rowp, T (&out)[4]) {
-        V4<T> q = *reinterpret_cast<const V4<T>*>(rowp);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = q.e[e];
-    };
-    auto lds_set = [&](T* rowp, const T (&in)[4]) {
-        V4<T> q;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) q.e[e] = in[e];
-        *reinterpret_cast<V4<T>*>(rowp) = q;
-    };
-    auto face4 = [&](const T (&u)[4], bool negate, T (&out)[4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = (ALIGNED || x0 + e <= W) ? (negate ? -u[e] : u[e]) : zero;
-    };
-    // publish a freshly computed row of level RG+1: the settled cells plus the ghosts its setBounds writes
-    auto publish = [&](auto rgc, auto wyc, int P, int r, const T (&u)[4], const T (&st)[4]) {
-        constexpr int RG = decltype(rgc)::value;
-        constexpr bool WALLY = decltype(wyc)::value != 0;
-        const int y = y0 + r, t = ty0 + r;
-        T(*tl)[TW] = ring[RG][P & 1];
-        lds_set(&tl[t][x0 + 3], st);
-        if (x0 == 1) tl[t][3] = (b == 1) ? -u[0] : u[0];                                          // :189-190
-        if (full_group && x0 + 3 == W) tl[t][W + 4] = u[3];                                       // :191
-        if (WALLY && (y == 1 || y == H)) {
-            T f[4];
-            face4(u, b == 2, f);
-            if (y == 1 && t >= 1) lds_set(&tl[t - 1][x0 + 3], f);                                  // :198-199
-            if (y == H && t + 1 < BY) lds_set(&tl[t + 1][x0 + 3], f);                              // :200-201
-        }
-    };
-
-    // level j+1 of plane P, row r, from the wave's level-j registers (planes P-1, P, P+1) and the
-    // level-j tile of plane P in LDS (x neighbours, and the y neighbours the wave does not own)
-    auto next_row = [&](auto rgc, auto wyc, int P, int r, const T (&s0)[RY][4], const T (&s1)[RY][4],
-                        const T (&s2)[RY][4], const T (&rh)[4], T (&u)[4]) {
-        constexpr int RG = decltype(rgc)::value;
-        constexpr bool WALLY = decltype(wyc)::value != 0;
-        const int y = y0 + r, t = ty0 + r;
-        T(*tl)[TW] = ring[RG][P & 1];
-        const T left = tl[t][x0 + 2];                    // neighbour lane's / wave's cell, or the ghost column x = 0
-        const T right = tl[t][x0 + 7];                   // ... or the ghost column x = W+1
-        T ym[4], yp[4];
-        if (r > 0 && !(WALLY && y == 1)) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ym[e] = s1[r > 0 ? r - 1 : 0][e];
-        } else lds_get(&tl[t - 1][x0 + 3], ym);          // another wave's row, or the ghost row y = 0
-        if (r < RY - 1 && !(WALLY && y == H)) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) yp[e] = s1[r < RY - 1 ? r + 1 : r][e];
-        } else lds_get(&tl[t + 1][x0 + 3], yp);          // another wave's row, or the ghost row y = H+1
-        relax4(s1[r], left, right, ym, yp, s0[r], s2[r], rh, u);
-    };
-
-    // final level: the stores of the sweep plus those of its setBounds
-    auto store_final = [&](auto wyc, auto wzc, int zo, int r, const T (&u)[4], unsigned fl) {
-        constexpr bool WALLY = decltype(wyc)::value != 0, WALLZ = decltype(wzc)::value != 0;
-        const int y = y0 + r;
-        T st[4];
-        settle4(u, fl, st);
-        char* base = reinterpret_cast<char*>(dst) + (long)zo * plane_b + oc[r];
-        V4<T> q;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) q.e[e] = st[e];
-        *reinterpret_cast<V4<T>*>(base) = q;
-        if (x0 == 1) *reinterpret_cast<T*>(base - 4) = (b == 1) ? -u[0] : u[0];                     // :189-190
-        if (full_group && x0 + 3 == W) *reinterpret_cast<T*>(base + 16) = u[3];                    // :191
-        if (WALLY && (y == 1 || y == H)) {
-            T f[4];
-            V4<T> qq;
-            face4(u, b == 2, f);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) qq.e[e] = f[e];
-            if (y == 1) *reinterpret_cast<V4<T>*>(base - (long)g.sy * 4) = qq;                      // :198-201
-            if (y == H) *reinterpret_cast<V4<T>*>(base + (long)g.sy * 4) = qq;
-        }
-        if (WALLZ && (zo == 1 || zo == D)) {
-            T f[4];
-            V4<T> qq;
-            face4(u, b == 3, f);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) qq.e[e] = f[e];
-            if (zo == 1) *reinterpret_cast<V4<T>*>(base - plane_b) = qq;                            // :208-214
-            if (zo == D) *reinterpret_cast<V4<T>*>(base + plane_b) = qq;
-        }
-    };
-
-    // One step of the march.  PH: which register slot is which plane (rotates with period 3);
-    // WALLY: this band touches the y = 1 or y = H wall; WALLZ: this iteration touches plane 1 or D
-    // at some level.  The common case (both false) carries no wall code at all.
-    auto iter = [&](auto phc, auto wyc, auto wzc, int zl) {
-        constexpr int PH = decltype(phc)::value;
-        constexpr bool WALLZ = decltype(wzc)::value != 0;
-        constexpr int I0 = PH, I1 = (PH + 1) % 3, I2 = (PH + 2) % 3;
-        // level-0 planes zl-1, zl, zl+1 sit in L0[I0], L0[I1], L0[I2]; level j planes
-        // p-1, p (and the one computed now, p+1) in Lj[I0], Lj[I1], Lj[I2]
-        // The row offsets are made opaque once per iteration: otherwise loop strength reduction folds
-        // each (plane pointer + row offset) into its own 64-bit vector induction variable -- two VGPRs
-        // per access kept across the loop -- instead of a scalar base plus this 32-bit offset.
-#pragma unroll
-        for (int r = 0; r < RY; ++r) asm volatile("" : "+v"(oc[r]));
-        if (zl <= hi1) {                                 // ---- level 1 of plane zl
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                const int y = y0 + r, t = ty0 + r;
-                const bool row_on = (y >= 1) && (y <= H);     // wave-uniform
-                if (row_on && lane_on) {
-                    T ym[4], yp[4], u[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ym[e] = (r > 0) ? L0[I1][r > 0 ? r - 1 : 0][e] : hb[e];
-                        yp[e] = (r < RY - 1) ? L0[I1][r < RY - 1 ? r + 1 : r][e] : ht[e];
-                    }
-                    relax4(L0[I1][r], eL[r], eR[r], ym, yp, L0[I0][r], L0[I2][r], rcur[r], u);
-                    settle4(u, flc[r], L1[I2][r]);
-                    publish(IC<0>{}, wyc, zl, r, u, L1[I2][r]);
-                    if (t >= 1 && t <= BY - 2) lds_set(&rsave[PH][t - 1][xl], rcur[r]);
-                    if (WALLZ && zl == 1) face4(u, b == 3, L1[I1][r]);      // ghost plane z = 0 takes plane 0's slot, :208-210
-                    if (WALLZ && zl == D) face4(u, b == 3, gz1[r]);         // ghost plane z = D+1 waits for its slot, :212-214
-                }
-                kl[PH][r] = flc[r];
-            }
-        }
-        // next plane's level-0 data, one iteration ahead.  Unconditional (a conditional load merges
-        // with the old register contents, and the merge waits for the load); past the last plane the
-        // same plane is fetched again and never used.
-        __builtin_amdgcn_sched_barrier(0);               // pin the loads here: left alone, the scheduler sinks them to the
-        load_core(min(zl + 2, D + 1), L0[I0]);           // end of the iteration to shorten live ranges, and the next
-        load_side(min(zl + 1, D));                       // iteration then starts by waiting a full memory latency
-        asm volatile("" ::: "memory");                   // (the IR-level sink pass does the same across blocks)
-        __builtin_amdgcn_sched_barrier(0);
-        const int P2 = zl - 1;
-        if (P2 >= lo2 && P2 <= hi2) {                    // ---- level 2 of plane zl-1
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                const int y = y0 + r, t = ty0 + r;
-                if (y >= r2lo && y <= r2hi) {            // wave-uniform
-                    T rh[4], u[4];
-                    lds_get(&rsave[I2][t - 1][xl], rh);
-                    next_row(IC<0>{}, wyc, P2, r, L1[I0], L1[I1], L1[I2], rh, u);
-                    if (lane_on) {
-                        settle4(u, kl[I2][r], L2[I2][r]);
-                        publish(IC<1>{}, wyc, P2, r, u, L2[I2][r]);
-                        if (WALLZ && P2 == 1) face4(u, b == 3, L2[I1][r]);
-                        if (WALLZ && P2 == D) face4(u, b == 3, gz2[r]);
-                    }
-                }
-            }
-        }
-        if (WALLZ && zl == D) {                          // level 1's oldest slot is free now: it becomes plane D+1
-#pragma unroll
-            for (int r = 0; r < RY; ++r)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) L1[I0][r][e] = gz1[r][e];
-        }
-        const int P3 = zl - 2;
-        if (P3 >= zbeg && P3 <= zend) {                  // ---- level 3 of plane zl-2
-#pragma unroll
-            for (int r = 0; r < RY; ++r) {
-                const int y = y0 + r, t = ty0 + r;
-                if (y >= r3lo && y <= r3hi) {
-                    T rh[4], u[4];
-                    lds_get(&rsave[I1][t - 1][xl], rh);
-                    next_row(IC<1>{}, wyc, P3, r, L2[I0], L2[I1], L2[I2], rh, u);
-                    if (lane_on) store_final(wyc, wzc, P3, r, u, kl[I1][r]);
-                }
-            }
-        }
-        if (WALLZ && P2 == D) {
-#pragma unroll
-            for (int r = 0; r < RY; ++r)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) L2[I0][r][e] = gz2[r][e];
-        }
-        __syncthreads();
-    };
-
-    load_core(lo1 - 1, L0[0]);
-    load_core(lo1, L0[1]);
-    load_core(lo1 + 1, L0[2]);
-    load_side(lo1);
-    const int zl_end = zend + 2;
-    auto march = [&](auto wyc) {
-        // an iteration touches a z wall at some level when zl <= 3 (planes 1 of levels 1..3) or zl >= D
-        auto step = [&](auto phc, int zl) {
-            iter(phc, wyc, IC<1>{}, zl);
-        };
-        int zl = lo1;
-        for (;;) {
-            step(IC<0>{}, zl);
-            if (++zl > zl_end) break;
-            step(IC<1>{}, zl);
-            if (++zl > zl_end) break;
-            step(IC<2>{}, zl);
-            if (++zl > zl_end) break;
-        }
-    };
-    march(IC<1>{});
-}
-
-template <int NXW, int NYW, int RY>
-static void launch_triple_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const float* src, const float* rhs,
-                            float* dst, const uint8_t* flags, int b, float a, float inv_c, int alt)
-{
-    constexpr int BY = NYW * RY;
-    const int planes = g.D;
-    // band k outputs rows k(BY-4)+2 .. k(BY-4)+BY-3 (band 0 from row 1, the last band up to row H)
-    const int nbands = (g.H <= BY - 3) ? 1 : (g.H - (BY - 3) + (BY - 4) - 1) / (BY - 4) + 1;
-    // z chunks re-read 6 level-0 planes and recompute 4+2 level-1/2 planes: same model as the pair launcher
-    int cand_nzc[3] = {1, 1, 1};
-    double cand_eff[3] = {-1.0, -1.0, -1.0};
-    const int slots = 256;
-    for (int nzc = 1; nzc <= 64 && (nzc == 1 || planes / nzc >= 16); ++nzc) {
-        const long blocks = (long)nbands * nzc;
-        const long rounds = (blocks + slots - 1) / slots;
-        const int len = (planes + nzc - 1) / nzc;
-        const double eff = (double)blocks / (double)(rounds * slots) * (double)len / (double)(len + 5);
-        for (int k = 0; k < 3; ++k)
-            if (eff > cand_eff[k] + 1e-9) {
-                for (int j = 2; j > k; --j) { cand_eff[j] = cand_eff[j - 1]; cand_nzc[j] = cand_nzc[j - 1]; }
-                cand_eff[k] = eff;
-                cand_nzc[k] = nzc;
-                break;
-            }
-    }
-    int pick = alt < 0 ? 0 : (alt > 2 ? 2 : alt);
-    while (pick > 0 && cand_eff[pick] < 0.0) --pick;
-    int zc_len = (planes + cand_nzc[pick] - 1) / cand_nzc[pick];
-    if (tune.pair_zc > 0) zc_len = tune.pair_zc < planes ? tune.pair_zc : planes;
-    const int nzc = (planes + zc_len - 1) / zc_len;
-    const int nblk = nbands * nzc;
-    if (g.W == NXW * 256)
-        hipLaunchKernelGGL((jacobi_triple_kernel<NXW, NYW, RY, true>), dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, src, rhs, dst,
-                           flags, b, a, inv_c, zc_len, nbands, nblk);
-    else
-        hipLaunchKernelGGL((jacobi_triple_kernel<NXW, NYW, RY, false>), dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, src, rhs, dst,
-                           flags, b, a, inv_c, zc_len, nbands, nblk);
-}
-
-template <>
-bool triple_supported<float>(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc)
-{
-    return sc.lo_wall && sc.hi_wall && g.W <= 512 && tune.fuse >= 3;
-}
-template <>
-bool triple_supported<double>(const SweepTune&, const GridDesc&, const SlabCtx&) { return false; }
-
-int triple_shape_count(const GridDesc& g) { return (g.W <= 256) ? 3 : 2; }
-
-void launch_jacobi_triple(hipStream_t st, const SweepTune& tune, const GridDesc& g, const float* src, const float* rhs,
-                          float* dst, const uint8_t* flags, int b, float a, float inv_c, int plan)
-{
-    // plan = workgroup shape + 8 * (which of the launcher's three best z-chunk counts); all plans give the
-    // same bits, the host driver times them once per grid.  Two rows per wave throughout (three rows and
-    // 8 waves were slower: the instruction stream of a wave is what limits this kernel).  Rows up to 256
-    // cells: bands of 20, 16 or 12 rows (the smaller ones trade recomputed rows for longer z chunks and,
-    // at 12 rows, two workgroups per CU); up to 512 cells: 12 or 10 rows.
-    if (plan < 0) plan = 0;
-    const int alt = plan >> 3, shape = plan & 7;
-    if (g.W <= 256) {
-        if (shape == 1) launch_triple_v<1, 8, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
-        else if (shape == 2) launch_triple_v<1, 6, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
-        else launch_triple_v<1, 10, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
-    } else {
-        if (shape == 1) launch_triple_v<2, 5, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
-        else launch_triple_v<2, 6, 2>(st, tune, g, src, rhs, dst, flags, b, a, inv_c, alt);
-    }
 }
 
 // =====================================================================================
@@ -1781,9 +1345,9 @@ __global__ void build_flags_kernel(GridDesc g, SlabCtx sc, const T* __restrict__
 template <class T>
 void launch_build_flags(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* obs, uint8_t* flags)
 {
-    // with two-deep halos the flags of the first halo plane on a slab side are needed too (the
-    // pair kernel recomputes level 1 of that plane); their z neighbours are the second halo plane
-    const int zlo = (g.zh >= 2 && !sc.lo_wall) ? 0 : 1, zhi = (g.zh >= 2 && !sc.hi_wall) ? g.D + 1 : g.D;
+    // with zh-deep halos the flags of the first zh-1 halo planes on a slab side are needed too (a fused
+    // pass recomputes the lower levels of those planes); the outermost halo plane only serves as their z neighbour
+    const int zlo = (g.zh >= 2 && !sc.lo_wall) ? 2 - g.zh : 1, zhi = (g.zh >= 2 && !sc.hi_wall) ? g.D + g.zh - 1 : g.D;
     dim3 grid = cell_grid(g);
     grid.z = zhi - zlo + 1;
     hipLaunchKernelGGL((build_flags_kernel<T>), grid, cell_block(), 0, st, g, sc, obs, flags, zlo);
@@ -1814,7 +1378,7 @@ __global__ void build_kill_kernel(GridDesc g, const uint8_t* __restrict__ flags,
 }
 void launch_build_kill(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, uint8_t* kill)
 {
-    const int zlo = (g.zh >= 2 && !sc.lo_wall) ? 0 : 1, zhi = (g.zh >= 2 && !sc.hi_wall) ? g.D + 1 : g.D;
+    const int zlo = (g.zh >= 2 && !sc.lo_wall) ? 2 - g.zh : 1, zhi = (g.zh >= 2 && !sc.hi_wall) ? g.D + g.zh - 1 : g.D;
     const int ng = (g.W + 3) / 4;
     hipLaunchKernelGGL(build_kill_kernel, dim3((ng + 63) / 64, (g.H + 3) / 4, zhi - zlo + 1), dim3(64, 4, 1), 0, st, g,
                        flags, kill, zlo);

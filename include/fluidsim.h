@@ -91,11 +91,13 @@ int fs_destroy(fs_sim* s);
  *   "profile"     "1" brackets each kernel family with HIP events (see fs_get_timing)
  *   "elide_dead_density_solve" "1" skips diffuse(0,dens,buffer) whose result the next
  *                 advect overwrites (simulation.cpp:135-136); default "0" = do it
- * Process-wide tuning keys that never change results (kernel selection and launch shapes):
+ * Per-handle tuning keys that never change results (kernel selection and launch shapes):
  *   "sweep_fuse"  "1" one solver sweep per pass over memory, "2" two, "3" (default) two or three: the
- *                 three-sweep kernel (fp32, single GPU, rows up to 512 cells) is timed against the
- *                 two-sweep one once per grid and used where a sweep costs less, "4" three wherever
- *                 that kernel exists;
+ *                 three-sweep kernel (fp32, rows up to 512 cells) is timed against the two-sweep one
+ *                 once per grid and used where a sweep costs less (z-slab ranks: always, so that all
+ *                 ranks keep one exchange schedule), "4" three wherever that kernel exists;
+ *   "two_sweep_kernel" "auto" (default: timed once per grid) | "pair" | "fused" -- which of the two
+ *                 two-sweep kernels (jacobi_pair_kernel / jacobi_fused_kernel<NL=2>) runs those passes;
  *   "sweep_ry" "sweep_zc" "sweep_blocks" "pair_zc" "pair_shape" "project_kernels" "fuse_advect"
  *   "overlap" -- see csrc/kernels.h (SweepTune) and tools/tune_*.py.
  */

@@ -25,6 +25,9 @@ def main():
     precision = sys.argv[11] if len(sys.argv) > 11 else "fp32"
     solver = sys.argv[12] if len(sys.argv) > 12 else "jacobi"
     extra = {"sor_omega": 1.6} if solver == "rbsor" else {}
+    for kv in (sys.argv[13].split(",") if len(sys.argv) > 13 and sys.argv[13] else []):   # further options, k=v,k=v
+        k, v = kv.split("=")
+        extra[k] = v
     sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_dir=os.path.join(outdir, "data"), dump_every=1,
                        voxel_seed=77, debug_poison_gather=1, precision=precision, solver=solver, **extra)
     if nranks > 1:
@@ -56,7 +59,8 @@ def main():
     out = {F.FIELD_NAMES[f]: sim.get(f) for f in (F.DENS, F.VX, F.VY, F.VZ, F.OBS, F.PRESSURE)}
     stats = np.array(sim.stats(F.DENS) + sim.stats(F.VX))
     reach = sim._geti("last_advect_reach")
-    np.savez(os.path.join(outdir, "rank%d.npz" % rank), zoff=zoff, stats=stats, reach=reach, **out)
+    kernels = np.array([sim._geti("triple_plan"), sim._geti("two_sweep_fused"), sim._geti("halo_depth")])
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), zoff=zoff, stats=stats, reach=reach, kernels=kernels, **out)
     sim.close()
 
 

@@ -100,6 +100,51 @@ def test_three_sweeps_per_pass_kernel_matches_oracle(F, oracle_mod, shape, acc):
         sim.set_option("sweep_fuse", "3")       # the option is process-wide: back to the default
 
 
+@pytest.mark.parametrize("shape,acc,fp64", [((24, 16, 12), 10, True), ((300, 20, 5), 4, True), ((512, 30, 9), 5, True),
+                                            ((14, 9, 7), 7, True), ((1, 1, 1), 3, True), ((509, 23, 6), 3, True),
+                                            ((600, 9, 7), 4, False), ((1000, 7, 6), 5, False), ((1024, 40, 12), 6, False),
+                                            ((800, 30, 20), 7, False), ((520, 3, 2), 2, False), ((768, 11, 40), 4, False)])
+def test_fused_two_sweep_kernel_matches_oracle(F, oracle_mod, shape, acc, fp64):
+    """two_sweep_kernel=fused runs the two-sweep passes as jacobi_fused_kernel<NL=2> (fp64 rows up to 512
+    cells; fp32 rows of 513..1024 cells) instead of leaving the choice to the clock: oracle Jacobi bit for
+    bit, corner solids next to all six walls, ragged rows, odd iteration counts."""
+    O = oracle_mod
+    W, H, D = shape
+    kw = dict(precision="fp64") if fp64 else {}
+    sim = F.Simulation(W, H, D, 1, acc=acc, solver="jacobi", quiet=1, two_sweep_kernel="fused", **kw)
+    ora = O.Oracle(W, H, D, solver=O.JACOBI, fp64=fp64, threads=4, acc=acc)
+    m = ball_mask(W, H, D, W / 3.0, H / 2.0, D / 2.0, min(W, H, D) / 4.0)
+    m[1, 1, 1] = m[D, H, W] = True
+    m[D // 2 + 1, 1, W // 2 + 1] = True
+    sim.set_mask(m)
+    ora.set_mask(m)
+    for _ in range(2):
+        sim.run_one()
+        ora.run_one()
+    if acc >= 2:
+        assert sim._geti("two_sweep_fused") == 1
+    same_state(F, O, sim, ora, "fused two-sweep kernel %s" % (shape,))
+
+
+def test_two_sweep_kernels_agree_at_benchmark_row_widths(F):
+    """jacobi_pair_kernel against jacobi_fused_kernel<NL=2> on the GPU at the row widths of configs 4 and 5
+    (lane-aligned variants): fp32 W = 1024, fp64 W = 512 and 256."""
+    for (W, H, D, acc, prec) in [(1024, 45, 31, 8, "fp32"), (512, 45, 31, 6, "fp64"), (256, 70, 20, 6, "fp64")]:
+        out = []
+        for kind in ("fused", "pair"):
+            sim = F.Simulation(W, H, D, 1, acc=acc, quiet=1, precision=prec, two_sweep_kernel=kind)
+            m = ball_mask(W, H, D, W / 3.0, H / 2.0, D / 2.0, min(H, D) / 3.0)
+            m[1, 1, 1] = m[D, H, W] = True
+            sim.set_mask(m)
+            sim.run_one()
+            sim.run_one()
+            assert sim._geti("two_sweep_fused") == (1 if kind == "fused" else 0)
+            out.append([sim.get(f) for f in range(11)])
+            sim.close()
+        for f in range(11):
+            assert bits_equal(out[0][f], out[1][f]), "%dx%dx%d %s %s" % (W, H, D, prec, F.FIELD_NAMES[f])
+
+
 def test_three_sweeps_per_pass_kernel_full_rows(F):
     """The same against the pair kernel on the GPU at the row widths the benchmark grids use
     (W = 256 and 512 take the lane-aligned variant of the kernel)."""

@@ -64,13 +64,17 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D):
         assert np.array_equal(a, b), fn
 
 
-@pytest.mark.parametrize("W,H,D,nranks,precision,solver",
-                         [(300, 9, 24, 2, "fp32", "jacobi"), (20, 12, 16, 2, "fp64", "jacobi"), (520, 7, 36, 3, "fp32", "jacobi"),
-                          (24, 11, 32, 2, "fp32", "rbsor"), (20, 9, 12, 3, "fp64", "rbsor")])
-def test_slabs_wide_rows_and_fp64(tmp_path, W, H, D, nranks, precision, solver):
-    """More than one 256-cell chunk per row (pair-kernel shapes 2xN / 3x4 on a slab), fp64 fields, and the
+@pytest.mark.parametrize("W,H,D,nranks,precision,solver,opts",
+                         [(300, 9, 24, 2, "fp32", "jacobi", ""), (20, 12, 16, 2, "fp64", "jacobi", ""), (520, 7, 36, 3, "fp32", "jacobi", ""),
+                          (24, 11, 32, 2, "fp32", "rbsor", ""), (20, 9, 12, 3, "fp64", "rbsor", ""),
+                          (520, 7, 36, 3, "fp32", "jacobi", "two_sweep_kernel=fused"), (1000, 5, 24, 2, "fp32", "jacobi", "two_sweep_kernel=fused"),
+                          (20, 12, 32, 2, "fp64", "jacobi", "two_sweep_kernel=fused"), (300, 9, 32, 2, "fp64", "jacobi", "two_sweep_kernel=fused"),
+                          (20, 12, 16, 2, "fp32", "jacobi", "two_sweep_kernel=pair"), (512, 6, 32, 2, "fp32", "jacobi", "")])
+def test_slabs_wide_rows_and_fp64(tmp_path, W, H, D, nranks, precision, solver, opts):
+    """More than one 256-cell chunk per row, fp64 fields, each of the solver kernels on a slab (fp32 rows up to
+    512 cells: three sweeps per pass across three-deep halos; the fused and the pair two-sweep kernel), and the
     optional red-black SOR solver (cell colour follows the global z, so slabs must agree with one GPU)."""
-    args = [W, H, D, 4, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision, solver]
+    args = [W, H, D, 7 if opts or W == 512 else 4, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision, solver, opts]
     ref_dir = run_ranks(str(tmp_path), 1, args)
     par_dir = run_ranks(str(tmp_path), nranks, args)
     ref = np.load(os.path.join(ref_dir, "rank0.npz"))
@@ -83,6 +87,12 @@ def test_slabs_wide_rows_and_fp64(tmp_path, W, H, D, nranks, precision, solver):
             got, want = z[k], ref[k][zoff:zoff + Dl + 2]
             assert got.dtype == want.dtype
             assert np.array_equal(got.view(u), want.view(u)), (r, k)
+        triple_plan, fused2, zh = (int(v) for v in z["kernels"])
+        if solver == "jacobi":
+            assert zh == (3 if precision == "fp32" and W <= 512 else 2)
+            assert (triple_plan >= 0) == (zh == 3)      # slab ranks run three sweeps per pass wherever the kernel exists
+            if "fused" in opts:
+                assert fused2 == 1
 
 
 def test_depth_must_divide(tmp_path):

@@ -31,8 +31,14 @@ if len(sys.argv) > 4:
     line = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
     stamp["pair_shape"] = line["roofline"]["workgroup_shape_id"]
     stamp["triple_plan"] = line["roofline"]["launch_plan_three_sweeps"]
-KEYS = ("jacobi_triple_kernel", "jacobi_pair_kernel", "jacobi_sweep_kernel", "advect_velocity_kernel", "advect_kernel", "divergence_march_kernel",
-        "gradient_march_kernel", "divergence_kernel", "gradient_kernel")
+import re  # noqa: E402
+
+# json key -> pattern of the kernel name as rocprofv3 prints it (first match wins)
+KEYS = (("jacobi_fused_kernel<NL=3>", r"jacobi_fused_kernel<\w+, 3,"), ("jacobi_fused_kernel<NL=2>", r"jacobi_fused_kernel<\w+, 2,"),
+        ("jacobi_pair_kernel", "jacobi_pair_kernel"), ("jacobi_sweep_kernel", "jacobi_sweep_kernel"),
+        ("advect_velocity_kernel", "advect_velocity_kernel"), ("advect_kernel", "advect_kernel"),
+        ("divergence_march_kernel", "divergence_march_kernel"), ("gradient_march_kernel", "gradient_march_kernel"),
+        ("divergence_kernel", "divergence_kernel"), ("gradient_kernel", "gradient_kernel"))
 
 
 def mean_by_kernel(d, counter):
@@ -40,9 +46,10 @@ def mean_by_kernel(d, counter):
     for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
-                for key in KEYS:
-                    if key in r["Kernel_Name"]:
+                for key, pat in KEYS:
+                    if re.search(pat, r["Kernel_Name"]):
                         acc[key].append(float(r["Counter_Value"]))
+                        break
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
