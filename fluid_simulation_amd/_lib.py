@@ -60,6 +60,9 @@ _SIGNATURES = {
     "fs_streamlines": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double,
                                  C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "fs_streamlines_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fs_obstacle_surface": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "fs_obstacle_surface_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fs_surface_case_table": (C.c_int, [C.c_int, C.c_void_p]),
     "fs_comm_unique_id": (C.c_int, [C.c_void_p]),
     "fs_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fs_comm_selftest": (C.c_int, []),

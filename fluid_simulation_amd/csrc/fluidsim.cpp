@@ -13,6 +13,7 @@
 #include "comm.h"
 #include "dump.h"
 #include "streamlines.h"
+#include "surface.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -81,6 +82,7 @@ struct EngineBase {
     virtual int tuned_triple() const = 0;
     virtual int halo_depth() const = 0;
     virtual int streamlines(int density, double proximity, int max_length, double step_size, double threshold) = 0;
+    virtual int obstacle_surface() = 0;
 };
 
 struct fs_sim {
@@ -119,6 +121,10 @@ struct fs_sim {
     // result of the last fs_streamlines call
     std::vector<long> sl_offsets;
     std::vector<double> sl_points, sl_norm;
+    // result of the last fs_obstacle_surface call
+    std::vector<float> surf_verts;
+    std::vector<int> surf_tris;
+    bool surf_valid = false;
     bool dump_async = true;
     fs::SweepTune tune;          // launch tunables of this handle (fs_set_option sweep_* / pair_* / project_kernels)
 
@@ -486,13 +492,23 @@ struct Engine : EngineBase {
         triple_alt = -1;
         int tmp = acquire(src, rhs);
         if (tmp < 0) return fail(FS_ENOMEM, "array pool exhausted");
-        struct Release {                                   // error paths must not leak the scratch array or the events
-            bool* held; int id; hipEvent_t e0 = nullptr, e1 = nullptr;
-            ~Release() { held[id] = false; if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+        struct Release {                                   // error paths must not leak the scratch arrays or the events
+            bool* held; int id, id2 = -1; hipEvent_t e0 = nullptr, e1 = nullptr;
+            ~Release() { held[id] = false; if (id2 >= 0) held[id2] = false; if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
         } rel{held, tmp};
+        if (src == rhs) {
+            // the first solve of a step reads iterate and right-hand side from ONE array (the snapshot alias): a
+            // third less HBM traffic than every later pass, which would rank the candidates for the wrong regime
+            const int copy = acquire(src, tmp);
+            if (copy < 0) return fail(FS_ENOMEM, "array pool exhausted");
+            rel.id2 = copy;
+            fs::launch_copy<T>(S->stream, g, arr[src], arr[copy]);
+            rhs = copy;
+        }
         HIP_TRY(hipEventCreate(&rel.e0));
         HIP_TRY(hipEventCreate(&rel.e1));
         hipEvent_t e0 = rel.e0, e1 = rel.e1;
+        const bool tune_log = getenv("FS_TUNE_LOG") != nullptr;   // development: print every candidate's time
         auto timed = [&](int levels, int cand, float* ms) -> int {
             const int keep_pair = pair_shape, keep_triple = triple_alt;
             if (levels == 3) triple_alt = cand; else pair_shape = cand;
@@ -506,6 +522,9 @@ struct Engine : EngineBase {
             }
             pair_shape = keep_pair;
             triple_alt = keep_triple;
+            if (tune_log && !rc)
+                fprintf(stderr, "fluidsim tune: %dx%dx%d %s levels=%d plan=%d  %.4f ms per pass\n", g.W, g.H, g.D,
+                        sizeof(T) == 8 ? "fp64" : "fp32", levels, cand, *ms);
             return rc;
         };
         float best = 1e30f;
@@ -994,6 +1013,31 @@ struct Engine : EngineBase {
             S->sl_points.insert(S->sl_points.end(), line.begin(), line.end());
             S->sl_offsets.push_back((long)(S->sl_points.size() / 3));
         }
+        return FS_OK;
+    }
+
+    // ---- the viewer's obstacle mesh (GUI/utils.py:10-38) ------------------------------------------
+    int obstacle_surface() override
+    {
+        S->surf_verts.clear();
+        S->surf_tris.clear();
+        S->surf_valid = false;
+        if (S->comm.active()) return fail(FS_EINVAL, "the obstacle surface is extracted on a single-GPU handle");
+        fs::SurfaceResult r;
+        const char* msg = "";
+        int rc = fs::extract_surface<T>(S->stream, g, arr[slot[FS_OBS]], &r, &msg);
+        if (rc) return fail(rc, "%s", msg);
+        S->surf_verts.resize((size_t)r.nverts * 3);
+        S->surf_tris.resize((size_t)r.ntris * 3);
+        hipError_t e = hipSuccess;
+        if (r.nverts > 0) {
+            e = hipMemcpyAsync(S->surf_verts.data(), r.d_verts, S->surf_verts.size() * sizeof(float), hipMemcpyDeviceToHost, S->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(S->surf_tris.data(), r.d_tris, S->surf_tris.size() * sizeof(int), hipMemcpyDeviceToHost, S->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
+        }
+        fs::surface_free(&r);
+        if (e != hipSuccess) return fail(FS_EHIP, "copying the obstacle surface: %s", hipGetErrorString(e));
+        S->surf_valid = true;
         return FS_OK;
     }
 
@@ -1531,6 +1575,33 @@ int fs_streamlines_fetch(fs_sim* s, long* offsets, double* points, double* norm_
     if (points && !s->sl_points.empty()) memcpy(points, s->sl_points.data(), s->sl_points.size() * sizeof(double));
     if (norm_speed && !s->sl_norm.empty()) memcpy(norm_speed, s->sl_norm.data(), s->sl_norm.size() * sizeof(double));
     return FS_OK;
+}
+
+int fs_obstacle_surface(fs_sim* s, long* n_vertices, long* n_triangles)
+{
+    ENGINE_OR_RETURN(s);
+    int rc = s->eng->obstacle_surface();
+    if (rc) return rc;
+    if (n_vertices) *n_vertices = (long)(s->surf_verts.size() / 3);
+    if (n_triangles) *n_triangles = (long)(s->surf_tris.size() / 3);
+    return FS_OK;
+}
+
+int fs_obstacle_surface_fetch(fs_sim* s, float* vertices, int* triangles)
+{
+    if (!s) return fail(FS_EINVAL, "null handle");
+    if (!s->surf_valid) return fail(FS_EINVAL, "fs_obstacle_surface has not been called");
+    if (vertices && !s->surf_verts.empty()) memcpy(vertices, s->surf_verts.data(), s->surf_verts.size() * sizeof(float));
+    if (triangles && !s->surf_tris.empty()) memcpy(triangles, s->surf_tris.data(), s->surf_tris.size() * sizeof(int));
+    return FS_OK;
+}
+
+int fs_surface_case_table(int config, int* edges)
+{
+    if (!edges) return fail(FS_EINVAL, "null buffer");
+    int n = fs::surface_case(config, edges);
+    if (n < 0) return fail(FS_EINVAL, "bad cube configuration %d (0..255)", config);
+    return n;
 }
 
 int fs_comm_unique_id(void* id_out)

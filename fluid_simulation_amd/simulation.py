@@ -176,6 +176,16 @@ class Simulation:
         check(self._L.fs_streamlines_fetch(self._h, off.ctypes.data, pts.ctypes.data, norm.ctypes.data))
         return [pts[off[i]:off[i + 1]].copy() for i in range(nl.value)], norm
 
+    def obstacle_surface(self):
+        """generate_obstacle_mesh of the reference's viewer (GUI/utils.py:10-38) from `obs` on the device:
+        (vertices (n, 3) float32 in the viewer's padded (x, y, z) index space, faces (m, 3) int32)."""
+        nv, nt = C.c_long(), C.c_long()
+        check(self._L.fs_obstacle_surface(self._h, C.byref(nv), C.byref(nt)))
+        verts = np.zeros((nv.value, 3), dtype=np.float32)
+        faces = np.zeros((nt.value, 3), dtype=np.int32)
+        check(self._L.fs_obstacle_surface_fetch(self._h, verts.ctypes.data, faces.ctypes.data))
+        return verts, faces
+
     def time_sweeps(self, b, field, prev, a, c, reps):
         ms = C.c_double()
         check(self._L.fs_time_sweeps(self._h, b, field, prev, a, c, reps, C.byref(ms)))

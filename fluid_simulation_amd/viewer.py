@@ -37,3 +37,24 @@ def generate_streamlines(vx, vy, vz, obs_data, max_length=100, density=30, proxi
     if cmap is None:
         return lines, list(norm)
     return lines, [np.array(cmap(float(v))) for v in norm]
+
+
+def generate_obstacle_mesh(obs_data):
+    """GUI/utils.py:10 `generate_obstacle_mesh` on the GPU: takes the padded obstacle array transposed to
+    (x, y, z) as GUI/main_window.py:204 passes it and returns the same dictionary ('vertexes', 'faces',
+    'vertex_colors' -- solid gray, utils.py:19-24; three empty arrays when there is no obstacle).  The mesh is
+    the 0.5 iso-surface like scikit-image's, but vertex / face order and the cut of ambiguous cubes are this
+    library's (parity unpinned: scikit-image is not available to compare with)."""
+    shape = tuple(int(n) - 2 for n in obs_data.shape)
+    if len(shape) != 3 or min(shape) < 1:
+        raise ValueError("expected the padded obstacle array (W+2, H+2, D+2)")
+    sim = _handles.get(shape)
+    if sim is None:
+        sim = _handles[shape] = Simulation(shape[0], shape[1], shape[2], 1, quiet=1, dump_every=0)
+    sim.set(_lib.OBS, np.ascontiguousarray(np.transpose(obs_data, (2, 1, 0)), dtype=np.float32))
+    verts, faces = sim.obstacle_surface()
+    if verts.shape[0] == 0:
+        return {"vertexes": np.array([]), "faces": np.array([]), "vertex_colors": np.array([])}
+    colors = np.ones((verts.shape[0], 4))
+    colors[:, :3] = 0.5
+    return {"vertexes": verts.astype(np.float64), "faces": faces, "vertex_colors": colors}

@@ -192,6 +192,24 @@ int fs_streamlines(fs_sim* s, int density, double proximity, int max_length, dou
  * Any of the three may be NULL. */
 int fs_streamlines_fetch(fs_sim* s, long* offsets, double* points, double* norm_speed);
 
+/* The obstacle mesh the reference's viewer builds on the CPU for the frame it shows --
+ * generate_obstacle_mesh, GUI/utils.py:10-38 (scikit-image marching cubes of `obs` at level 0.5),
+ * called from GUI/main_window.py:204-218 -- from `obs` as it is on the device: an indexed triangle mesh,
+ * one vertex per grid edge on which obs crosses 0.5 (linear interpolation; for a 0/1 mask the edge
+ * midpoint), in the viewer's coordinates (indices into the padded array, x first).  Closed, oriented
+ * with normals from solid to fluid.  PARITY UNPINNED against scikit-image (vertex / triangle order and
+ * the cut of ambiguous cubes may differ; see csrc/surface.h).  The result stays in the handle until
+ * the next call.  Single-GPU handles only. */
+int fs_obstacle_surface(fs_sim* s, long* n_vertices, long* n_triangles);
+/* Copies the last result: vertices[3 * n_vertices] (x, y, z), triangles[3 * n_triangles] (vertex
+ * indices).  Either may be NULL. */
+int fs_obstacle_surface_fetch(fs_sim* s, float* vertices, int* triangles);
+/* The triangle table behind it, for one cube configuration (bit i set: corner
+ * (i & 1, (i >> 1) & 1, (i >> 2) & 1) is solid): writes 3 cube-edge ids per triangle into
+ * edges[24] and returns the triangle count (0..8); edge id = 4 * axis + 2 * (offset on the higher
+ * other axis) + (offset on the lower other axis).  Needs neither a handle nor a GPU. */
+int fs_surface_case_table(int config, int* edges);
+
 /* ---- multi-GPU z-slabs (one process per GPU; RCCL halo exchange over xGMI) -------- */
 
 /* Size of the opaque RCCL unique id; rank 0 fills it with fs_comm_unique_id and the

@@ -67,9 +67,9 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D):
 @pytest.mark.parametrize("W,H,D,nranks,precision,solver,opts",
                          [(300, 9, 24, 2, "fp32", "jacobi", ""), (20, 12, 16, 2, "fp64", "jacobi", ""), (520, 7, 36, 3, "fp32", "jacobi", ""),
                           (24, 11, 32, 2, "fp32", "rbsor", ""), (20, 9, 12, 3, "fp64", "rbsor", ""),
-                          (520, 7, 36, 3, "fp32", "jacobi", "two_sweep_kernel=fused"), (1000, 5, 24, 2, "fp32", "jacobi", "two_sweep_kernel=fused"),
+                          (520, 7, 36, 3, "fp32", "jacobi", "two_sweep_kernel=fused"), (1000, 8, 24, 2, "fp32", "jacobi", "two_sweep_kernel=fused"),
                           (20, 12, 32, 2, "fp64", "jacobi", "two_sweep_kernel=fused"), (300, 9, 32, 2, "fp64", "jacobi", "two_sweep_kernel=fused"),
-                          (20, 12, 16, 2, "fp32", "jacobi", "two_sweep_kernel=pair"), (512, 6, 32, 2, "fp32", "jacobi", "")])
+                          (20, 12, 16, 2, "fp32", "jacobi", "two_sweep_kernel=pair"), (512, 8, 32, 2, "fp32", "jacobi", "")])
 def test_slabs_wide_rows_and_fp64(tmp_path, W, H, D, nranks, precision, solver, opts):
     """More than one 256-cell chunk per row, fp64 fields, each of the solver kernels on a slab (fp32 rows up to
     512 cells: three sweeps per pass across three-deep halos; the fused and the pair two-sweep kernel), and the
