@@ -195,6 +195,7 @@ struct Engine : EngineBase {
     T* gathered = nullptr;              // gathered advection source (z-slabs only), LEAD-shifted global array
     T* gathered3[3] = {nullptr, nullptr, nullptr};   // the same for the three sources of the fused velocity advection
     double* red = nullptr;              // stats scratch
+    T* coltab = nullptr;                // clamp tables of the advection row kernels: 6 x (H+2)(D+2) (single GPU only)
     static constexpr int FUSED2 = 64;   // pair_shape >= FUSED2: the two-sweep passes run jacobi_fused_kernel<NL = 2>, plan id - FUSED2
     int pair_shape = -1;                // fastest two-sweep launch plan for this grid (timed once)
     int tuned_fuse = -1, tuned_pair_shape_opt = -1;   // option values the two choices here were timed under
@@ -251,6 +252,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipMemsetAsync(kb, 0, g.n / 4 + 16, S->stream));
         kill = kb + (g.lead - fs::LEAD) / 4;
         HIP_TRY(hipMalloc((void**)&red, NRED * sizeof(double)));
+        if (!cm.active()) HIP_TRY(hipMalloc((void**)&coltab, sizeof(T) * 6 * (size_t)(g.H + 2) * (size_t)(g.D + 2)));
         if (cm.active()) {
             int lo_pri = 0, hi_pri = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
@@ -272,6 +274,7 @@ struct Engine : EngineBase {
             if (gp) hipFree(gp - fs::LEAD);
         if (dense) hipFree(dense);
         if (red) hipFree(red);
+        if (coltab) hipFree(coltab);
         if (ev_edges) hipEventDestroy(ev_edges);
         if (ev_halo) hipEventDestroy(ev_halo);
         if (comm_stream) hipStreamDestroy(comm_stream);
@@ -684,8 +687,8 @@ struct Engine : EngineBase {
         }
         {
             ScopedSpan sp(S, FAM_ADVECT);
-            fs::launch_advect<T>(S->stream, g, sc, b, arr[slot[field]], src, arr[slot[FS_VX]], arr[slot[FS_VY]],
-                                 arr[slot[FS_VZ]], flags, kx, ky, kz, zshift);
+            fs::launch_advect<T>(S->stream, S->tune, g, sc, b, arr[slot[field]], src, arr[slot[FS_VX]], arr[slot[FS_VY]],
+                                 arr[slot[FS_VZ]], flags, kill, coltab, kx, ky, kz, zshift);
         }
         return halo(arr[slot[field]]);
     }
@@ -744,8 +747,8 @@ struct Engine : EngineBase {
         }
         {
             ScopedSpan sp(S, FAM_ADVECT);
-            fs::launch_advect_velocity<T>(S->stream, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]], p[0], p[1],
-                                          p[2], flags, kx, ky, kz, zshift);
+            fs::launch_advect_velocity<T>(S->stream, S->tune, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]], p[0], p[1],
+                                          p[2], flags, kill, coltab, kx, ky, kz, zshift);
         }
         for (int f : { FS_VX, FS_VY, FS_VZ })
             if ((rc = halo(arr[slot[f]]))) return rc;
@@ -1301,6 +1304,10 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         if (v == "cell") s->tune.project_cell = 1;
         else if (v == "march") s->tune.project_cell = 0;
         else return fail(FS_EINVAL, "project_kernels: march | cell");
+    } else if (k == "advect_kernels") {
+        if (v == "cell") s->tune.advect_cell = 1;
+        else if (v == "row") s->tune.advect_cell = 0;
+        else return fail(FS_EINVAL, "advect_kernels: row | cell");
     } else if (k == "pair_zc") {
         s->tune.pair_zc = atoi(value);
     } else if (k == "pair_shape") {

@@ -50,6 +50,7 @@ struct SweepTune {
     int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic
     int project_cell = 0;     // 1 = per-cell divergence/gradient kernels instead of the z-marching ones
     int pair_shape = 0;       // >0 forces a pair-kernel workgroup shape (1 = 8, 2 = 10, 3 = 16 waves); 0 = timed choice
+    int advect_cell = 0;      // 1 = per-cell advection kernels instead of the row kernels (four cells per lane + clamp tables)
     int two_kind = 0;         // which two-sweep kernel: 0 = timed choice, 1 = jacobi_pair_kernel only, 2 = jacobi_fused_kernel<NL=2> only
 };
 
@@ -102,15 +103,19 @@ void launch_gradient(hipStream_t st, const SweepTune& tune, const GridDesc& g, c
 
 // `prev_zshift` = element offset added to local indices of `prev` (0 normally; under
 // z-slabs `prev` is the all-gathered global array and the shift is zoff planes).
+// `kill` = the kill-byte array, `coltab` = scratch for the clamp tables of the row kernels: 6 * (H+2) * (D+2)
+// elements, or nullptr (no tables; also ignored on slabs).  tune.advect_cell selects the per-cell kernels.
 template <class T>
-void launch_advect(hipStream_t st, const GridDesc& g, const SlabCtx& sc, int b, T* field, const T* prev, const T* vx,
-                   const T* vy, const T* vz, const uint8_t* flags, T kx, T ky, T kz, long prev_zshift);
+void launch_advect(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int b, T* field, const T* prev,
+                   const T* vx, const T* vy, const T* vz, const uint8_t* flags, const uint8_t* kill, T* coltab, T kx, T ky, T kz,
+                   long prev_zshift);
 
 // advect(1,vx,px); advect(2,vy,py); advect(3,vz,pz) in one pass.  On a slab px/py/pz are the
 // gathered global arrays and zshift the element offset of this slab's plane 0 in them.
 template <class T>
-void launch_advect_velocity(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz, const T* px,
-                            const T* py, const T* pz, const uint8_t* flags, T kx, T ky, T kz, long zshift);
+void launch_advect_velocity(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz,
+                            const T* px, const T* py, const T* pz, const uint8_t* flags, const uint8_t* kill, T* coltab, T kx,
+                            T ky, T kz, long zshift);
 
 template <class T>
 void launch_build_flags(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* obs, uint8_t* flags);

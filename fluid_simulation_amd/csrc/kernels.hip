@@ -1279,32 +1279,197 @@ __global__ __launch_bounds__(256) void advect_velocity_kernel(GridDesc g, SlabCt
     write_face_ghosts(g, sc, vz, c, x, y, z, nz, 3);
 }
 
+// ---- row forms of the two advection kernels (the default) ------------------------------------------
+// Same arithmetic, restructured around what the memory system sees:
+//  * a lane owns four x-consecutive cells: the velocities, the cell's own source values and the result move as
+//    one dwordx4 each (a wave = 1 KiB of a row per stream), the solid / near-solid tests come from the kill byte
+//    (one byte per four cells) instead of four flag bytes;
+//  * the back-trace is data-dependent, but in a wind tunnel most of it is not: dt*W*u_x is hundreds of cells
+//    (SURVEY 7.3-3), so the x coordinate of almost every trace clamps to 0.5 -- x0 = 0, weight exactly 0.5
+//    (:388, :392-401) -- and the x interpolation (:412-415) only ever combines the ghost column x = 0 with
+//    x = 1 (or x = W with W+1 at the other clamp).  advect_columns_kernel does that interpolation once per
+//    (y, z) into two small tables (2 x (H+2)(D+2) values per source field, L2-resident); a clamped trace then
+//    reads 4 table values as two 8-byte loads instead of 8 scattered values of the big array.  Same
+//    expression, same operands, same rounding: bit-identical with the per-cell kernels (tests).
+// Traces that do not clamp gather as before.  Wave shuffles do not apply here: which lanes share source rows
+// depends on the velocities.
 template <class T>
-void launch_advect_velocity(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz, const T* px,
-                            const T* py, const T* pz, const uint8_t* flags, T kx, T ky, T kz, long zshift)
+__global__ __launch_bounds__(256) void advect_columns_kernel(GridDesc g, const T* __restrict__ p0, const T* __restrict__ p1,
+                                                              const T* __restrict__ p2, int nsrc, T* __restrict__ tab)
 {
-    hipLaunchKernelGGL((advect_velocity_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, px, py, pz, flags,
-                       kx, ky, kz, zshift);
+    // tab[(2*k + side) * (H+2)(D+2) + y + z*(H+2)]: source k, side 0 = columns (0, 1), side 1 = columns (W, W+1)
+    const long plane = (long)(g.H + 2) * (g.D + 2);
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const int y = (int)(i % (g.H + 2)), z = (int)(i / (g.H + 2));
+    const T one = (T)1, half = (T)0.5;
+    for (int k = 0; k < nsrc; ++k) {
+        const T* s = (k == 0 ? p0 : k == 1 ? p1 : p2) + cell(g, 0, y, z);
+        tab[(2 * k + 0) * plane + i] = s[0] * (one - half) + s[1] * half;                 // :412-415 with tx = 0.5
+        tab[(2 * k + 1) * plane + i] = s[g.W] * (one - half) + s[g.W + 1] * half;
+    }
 }
-template void launch_advect_velocity<float>(hipStream_t, const GridDesc&, const SlabCtx&, float*, float*, float*,
-                                            const float*, const float*, const float*, const uint8_t*, float, float, float,
-                                            long);
-template void launch_advect_velocity<double>(hipStream_t, const GridDesc&, const SlabCtx&, double*, double*, double*,
-                                             const double*, const double*, const double*, const uint8_t*, double, double,
-                                             double, long);
 
 template <class T>
-void launch_advect(hipStream_t st, const GridDesc& g, const SlabCtx& sc, int b, T* field, const T* prev, const T* vx,
-                   const T* vy, const T* vz, const uint8_t* flags, T kx, T ky, T kz, long prev_zshift)
+__device__ __forceinline__ T back_trace_tab(const GridDesc& g, const SlabCtx& sc, const T* __restrict__ src, long zshift,
+                                            const T* __restrict__ tab, int x, int y, int z, T ux, T uy, T uz, T kx, T ky, T kz)
 {
-    hipLaunchKernelGGL((advect_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, b, field, prev, vx, vy, vz, flags,
-                       kx, ky, kz, prev_zshift);
+    const T one = (T)1, half = (T)0.5;
+    const T px = clamp_ref<T>((T)x - kx * ux, half, (T)g.W + half);          // :384-390
+    const T py = clamp_ref<T>((T)y - ky * uy, half, (T)g.H + half);
+    const T pz = clamp_ref<T>((T)(z + sc.zoff) - kz * uz, half, (T)sc.Dglobal + half);
+    const int y0 = (int)floor(py), z0 = (int)floor(pz);
+    const T ty = py - (T)y0, tz = pz - (T)z0;
+    T a00, a01, a10, a11;
+    const bool lo = (px == half), hi = (px == (T)g.W + half);
+    if (tab != nullptr && (lo || hi)) {
+        // x0 = 0 (or W) and tx = 0.5 exactly: the x interpolation was done by advect_columns_kernel
+        const long plane = (long)(g.H + 2) * (g.D + 2);
+        const T* t = tab + (hi ? plane : 0) + y0 + (long)z0 * (g.H + 2);
+        a00 = t[0];
+        a10 = t[1];
+        a01 = t[g.H + 2];
+        a11 = t[g.H + 3];
+    } else {
+        const int x0 = (int)floor(px);
+        const T tx = px - (T)x0;
+        const T* s = src + zshift + cell(g, x0, y0, z0 - sc.zoff);
+        a00 = s[0] * (one - tx) + s[1] * tx;                                  // :412-415
+        a01 = s[g.sz] * (one - tx) + s[g.sz + 1] * tx;
+        a10 = s[g.sy] * (one - tx) + s[g.sy + 1] * tx;
+        a11 = s[g.sy + g.sz] * (one - tx) + s[g.sy + g.sz + 1] * tx;
+    }
+    const T b0 = a00 * (one - ty) + a10 * ty;                                 // :417-418
+    const T b1 = a01 * (one - ty) + a11 * ty;
+    return b0 * (one - tz) + b1 * tz;                                         // :420
 }
-template void launch_advect<float>(hipStream_t, const GridDesc&, const SlabCtx&, int, float*, const float*, const float*,
-                                   const float*, const float*, const uint8_t*, float, float, float, long);
-template void launch_advect<double>(hipStream_t, const GridDesc&, const SlabCtx&, int, double*, const double*,
-                                    const double*, const double*, const double*, const uint8_t*, double, double, double,
-                                    long);
+
+// advect(b, field, prev) + setBounds(b, field): four cells per lane
+template <class T>
+__global__ __launch_bounds__(256) void advect_row_kernel(GridDesc g, SlabCtx sc, int b, T* __restrict__ field,
+                                                          const T* __restrict__ prev, const T* vx, const T* vy, const T* vz,
+                                                          const uint8_t* __restrict__ kill, const T* __restrict__ tab, T kx,
+                                                          T ky, T kz, long zshift)
+{
+    const int x0 = 1 + (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = 1 + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // a wave is one row
+    const int z = 1 + blockIdx.z;
+    if (x0 > g.W || y > g.H) return;
+    const long c = cell(g, x0, y, z);
+    const unsigned kb = kill[(c + 3) >> 2];              // bits 0-3 solid, bits 4-7 solid or next to a solid
+    T own[4], ax[4], ay[4], az[4], u[4];
+    ld_row(prev + c + zshift, b != 0, own);
+    ld_row(vx + c, b != 1, ax);
+    ld_row(vy + c, b != 2, ay);
+    ld_row(vz + c, b != 3, az);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u[e] = (T)0;                                     // solid cells: 0 (:375-377)
+        if (x0 + e <= g.W && !((kb >> e) & 1u)) {
+            const T ux = (b == 1) ? own[e] : ax[e];      // :380-382
+            const T uy = (b == 2) ? own[e] : ay[e];
+            const T uz = (b == 3) ? own[e] : az[e];
+            u[e] = back_trace_tab<T>(g, sc, prev, zshift, tab, x0 + e, y, z, ux, uy, uz, kx, ky, kz);
+        }
+    }
+    store_row_bounds<T>(g, sc, field, c, x0, y, z, u, (b == 0) ? (kb & 15u) : (kb >> 4), b);
+}
+
+// the three velocity advections of a step in one pass (see advect_velocity_kernel): four cells per lane
+template <class T>
+__global__ __launch_bounds__(256) void advect_velocity_row_kernel(GridDesc g, SlabCtx sc, T* __restrict__ vx, T* __restrict__ vy,
+                                                                   T* __restrict__ vz, const T* __restrict__ px,
+                                                                   const T* __restrict__ py, const T* __restrict__ pz,
+                                                                   const uint8_t* __restrict__ kill, const T* __restrict__ tab,
+                                                                   T kx, T ky, T kz, long zshift)
+{
+    const int x0 = 1 + (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = 1 + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int z = 1 + blockIdx.z;
+    if (x0 > g.W || y > g.H) return;
+    const long c = cell(g, x0, y, z);
+    const unsigned kb = kill[(c + 3) >> 2];
+    const unsigned near4 = kb >> 4;
+    const long plane2 = 2 * (long)(g.H + 2) * (g.D + 2);
+    const T* tx_ = tab, *ty_ = tab ? tab + plane2 : nullptr, *tz_ = tab ? tab + 2 * plane2 : nullptr;
+    T ox[4], oy[4], oz[4], qy[4], qz[4], nx[4], ny[4], nz[4];
+    ld_row(px + c + zshift, true, ox);
+    ld_row(py + c + zshift, true, qy);
+    ld_row(pz + c + zshift, true, qz);
+    ld_row(vy + c, true, oy);
+    ld_row(vz + c, true, oz);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        nx[e] = ny[e] = nz[e] = (T)0;                    // un-zeroed results (0 inside solids, :375-377)
+        if (x0 + e <= g.W && !((kb >> e) & 1u)) {
+            const bool near = ((near4 >> e) & 1u) != 0;
+            nx[e] = back_trace_tab<T>(g, sc, px, zshift, tx_, x0 + e, y, z, ox[e], oy[e], oz[e], kx, ky, kz);
+            const T sx = near ? (T)0 : nx[e];            // what setBounds leaves in v_x
+            ny[e] = back_trace_tab<T>(g, sc, py, zshift, ty_, x0 + e, y, z, sx, qy[e], oz[e], kx, ky, kz);
+            const T sy = near ? (T)0 : ny[e];
+            nz[e] = back_trace_tab<T>(g, sc, pz, zshift, tz_, x0 + e, y, z, sx, sy, qz[e], kx, ky, kz);
+        }
+    }
+    store_row_bounds<T>(g, sc, vx, c, x0, y, z, nx, near4, 1);
+    store_row_bounds<T>(g, sc, vy, c, x0, y, z, ny, near4, 2);
+    store_row_bounds<T>(g, sc, vz, c, x0, y, z, nz, near4, 3);
+}
+
+static inline dim3 row_grid(const GridDesc& g) { return dim3((g.W + 255) / 256, (g.H + 3) / 4, g.D); }
+
+// the clamp tables only describe a source array that is this GPU's whole domain (a slab traces into the gathered array)
+template <class T>
+static const T* build_columns(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const T* p0, const T* p1, const T* p2,
+                              int nsrc, T* coltab, long zshift)
+{
+    if (!coltab || zshift != 0 || !(sc.lo_wall && sc.hi_wall)) return nullptr;
+    const long plane = (long)(g.H + 2) * (g.D + 2);
+    hipLaunchKernelGGL((advect_columns_kernel<T>), dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, g, p0, p1, p2, nsrc,
+                       coltab);
+    return coltab;
+}
+
+template <class T>
+void launch_advect_velocity(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, T* vx, T* vy, T* vz,
+                            const T* px, const T* py, const T* pz, const uint8_t* flags, const uint8_t* kill, T* coltab, T kx,
+                            T ky, T kz, long zshift)
+{
+    if (tune.advect_cell) {
+        hipLaunchKernelGGL((advect_velocity_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, px, py, pz, flags,
+                           kx, ky, kz, zshift);
+        return;
+    }
+    const T* tab = build_columns<T>(st, g, sc, px, py, pz, 3, coltab, zshift);
+    hipLaunchKernelGGL((advect_velocity_row_kernel<T>), row_grid(g), dim3(256), 0, st, g, sc, vx, vy, vz, px, py, pz, kill, tab,
+                       kx, ky, kz, zshift);
+}
+template void launch_advect_velocity<float>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, float*, float*,
+                                            float*, const float*, const float*, const float*, const uint8_t*, const uint8_t*,
+                                            float*, float, float, float, long);
+template void launch_advect_velocity<double>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, double*, double*,
+                                             double*, const double*, const double*, const double*, const uint8_t*,
+                                             const uint8_t*, double*, double, double, double, long);
+
+template <class T>
+void launch_advect(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int b, T* field, const T* prev,
+                   const T* vx, const T* vy, const T* vz, const uint8_t* flags, const uint8_t* kill, T* coltab, T kx, T ky, T kz,
+                   long prev_zshift)
+{
+    if (tune.advect_cell) {
+        hipLaunchKernelGGL((advect_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, b, field, prev, vx, vy, vz, flags,
+                           kx, ky, kz, prev_zshift);
+        return;
+    }
+    const T* tab = build_columns<T>(st, g, sc, prev, prev, prev, 1, coltab, prev_zshift);
+    hipLaunchKernelGGL((advect_row_kernel<T>), row_grid(g), dim3(256), 0, st, g, sc, b, field, prev, vx, vy, vz, kill, tab, kx,
+                       ky, kz, prev_zshift);
+}
+template void launch_advect<float>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, int, float*, const float*,
+                                   const float*, const float*, const float*, const uint8_t*, const uint8_t*, float*, float, float,
+                                   float, long);
+template void launch_advect<double>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, int, double*, const double*,
+                                    const double*, const double*, const double*, const uint8_t*, const uint8_t*, double*, double,
+                                    double, double, long);
 
 // =====================================================================================
 // Flag bytes from the obstacle array.  Tests follow the reference literally:

@@ -145,6 +145,35 @@ def test_two_sweep_kernels_agree_at_benchmark_row_widths(F):
             assert bits_equal(out[0][f], out[1][f]), "%dx%dx%d %s %s" % (W, H, D, prec, F.FIELD_NAMES[f])
 
 
+@pytest.mark.parametrize("speed,shape,fp64", [(30, (70, 33, 21), False), (1, (70, 33, 21), False), (-20, (66, 20, 17), False),
+                                              (30, (300, 12, 9), True), (2, (23, 9, 40), True)])
+def test_advection_row_kernels_match_cell_kernels_and_oracle(F, oracle_mod, speed, shape, fp64):
+    """The default advection kernels (four cells per lane; traces whose x coordinate clamps read the
+    pre-interpolated inlet / outlet column tables) against the per-cell kernels and the oracle: inlet speed 30
+    (every trace clamps low), 1 (hardly any does), negative (clamps at the outlet side), ragged row ends."""
+    O = oracle_mod
+    W, H, D = shape
+    kw = dict(precision="fp64") if fp64 else {}
+    m = ball_mask(W, H, D, W / 3.0, H / 2.0, D / 2.0, min(W, H, D) / 4.0)
+    m[1, 1, 1] = m[D, H, W] = True
+    sims = [F.Simulation(W, H, D, 1, speed=speed, acc=4, quiet=1, advect_kernels=k, **kw) for k in ("row", "cell")]
+    ora = O.Oracle(W, H, D, solver=O.JACOBI, fp64=fp64, threads=4, speed=speed, acc=4)
+    for x in sims + [ora]:
+        x.set_mask(m)
+    for _ in range(3):
+        for x in sims + [ora]:
+            x.run_one()
+    for f in range(11):
+        assert bits_equal(sims[0].get(f), sims[1].get(f)), "row vs cell: %s" % F.FIELD_NAMES[f]
+    same_state(F, O, sims[0], ora, "advection row kernels, speed %d" % speed)
+    sims[0].set_option("fuse_advect", "0")               # the three velocity advections as separate launches
+    sims[1].set_option("fuse_advect", "0")
+    for x in sims + [ora]:
+        x.run_one()
+    same_state(F, O, sims[0], ora, "unfused row kernels, speed %d" % speed)
+    same_state(F, O, sims[1], ora, "unfused cell kernels, speed %d" % speed)
+
+
 def test_three_sweeps_per_pass_kernel_full_rows(F):
     """The same against the pair kernel on the GPU at the row widths the benchmark grids use
     (W = 256 and 512 take the lane-aligned variant of the kernel)."""
