@@ -1279,7 +1279,13 @@ __global__ __launch_bounds__(256) void advect_velocity_kernel(GridDesc g, SlabCt
     write_face_ghosts(g, sc, vz, c, x, y, z, nz, 3);
 }
 
-// ---- row forms of the two advection kernels (the default) ------------------------------------------
+// ---- row forms of the two advection kernels (option advect_kernels=row; NOT the default) ------------
+// Measured slower than the per-cell kernels above on MI355X (512^3: 2.8 against 2.4 ms per step fp32, 5.0
+// against 3.5 fp64, profiles/r02g_advect_row_vs_cell_*.json): the per-cell form already gets what this form
+// was built for -- a wave's 64 clamped traces land on the same two or three cache lines of the inlet column,
+// so its gathers coalesce by themselves -- and it keeps four times as many waves in flight to hide the
+// latency of the dependent gather.  Kept because it is exercised by the tests (bit-identical) and documents
+// the experiment.
 // Same arithmetic, restructured around what the memory system sees:
 //  * a lane owns four x-consecutive cells: the velocities, the cell's own source values and the result move as
 //    one dwordx4 each (a wave = 1 KiB of a row per stream), the solid / near-solid tests come from the kill byte

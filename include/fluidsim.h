@@ -98,7 +98,7 @@ int fs_destroy(fs_sim* s);
  *                 ranks keep one exchange schedule), "4" three wherever that kernel exists;
  *   "two_sweep_kernel" "auto" (default: timed once per grid) | "pair" | "fused" -- which of the two
  *                 two-sweep kernels (jacobi_pair_kernel / jacobi_fused_kernel<NL=2>) runs those passes;
- *   "advect_kernels" "row" (default: four cells per lane, clamp tables) | "cell" (one thread per cell);
+ *   "advect_kernels" "cell" (default: one thread per cell) | "row" (four cells per lane, clamp tables; slower);
  *   "sweep_ry" "sweep_zc" "sweep_blocks" "pair_zc" "pair_shape" "project_kernels" "fuse_advect"
  *   "overlap" -- see csrc/kernels.h (SweepTune) and tools/tune_*.py.
  */
