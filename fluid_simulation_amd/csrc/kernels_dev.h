@@ -25,4 +25,26 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblk)
     return k * q + (k < r ? k : r) + (b >> 3);
 }
 
+// Kernel-argument form of EdgeFirst: nblocks leading workgroups are boundary chunks of `planes` planes each, the first
+// `nbands` of them for the region starting at `first`, the next `nbands` (if any) for the one starting at `second`.
+struct EdgeArgs {
+    int nblocks, first, second, planes;
+    unsigned* counter;
+};
+
+// A boundary workgroup has stored its planes: make them visible to the device (the halo exchange runs in another
+// kernel, possibly while this one is still computing the interior) and count the workgroup in.
+// Every storing wave drains its stores, the workgroup meets, one lane writes back L2 and signals
+// (/opt/skills/guides/MI355X_MICROARCH.md, "Valid forms": plain stores + release fence + relaxed agent atomic).
+__device__ __forceinline__ void edge_signal(unsigned* counter)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace fs
