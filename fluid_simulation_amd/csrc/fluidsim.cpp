@@ -99,8 +99,9 @@ struct fs_sim {
     unsigned voxel_seed = 1;
     bool quiet = false, profile = false, elide_dead = false;
     bool fuse_advect = true;     // one kernel for the three velocity advections of a step (single GPU)
-    bool overlap = true;         // z-slabs: exchange boundary planes while the interior is computed
-    bool edge_merge = true;      // ... with the boundary planes computed by the leading workgroups of the interior launch
+    int overlap = 1;             // z-slabs: exchange boundary planes while the interior is computed (1: boundary launch, then
+                                 // interior launch, one stream; 2: boundary + exchange on the communication stream beside the interior)
+    bool edge_merge = false;      // ... with the boundary planes computed by the leading workgroups of the interior launch
     bool debug_poison = false;   // fill the gathered advection source with NaN bit patterns before each gather
     int last_reach = 0;          // planes of reach used by the most recent slab advection
     // device
@@ -203,9 +204,10 @@ struct Engine : EngineBase {
     int tuned_fuse = -1, tuned_pair_shape_opt = -1;   // option values the two choices here were timed under
     int triple_alt = -1;                // >= 0: three sweeps per pass beat two on this grid (launch plan id)
     hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
-    hipEvent_t ev_edges = nullptr, ev_halo = nullptr;
-    unsigned* edge_counter = nullptr;   // signal word the boundary workgroups of a pass count themselves into (z-slabs)
-    unsigned edge_target = 0;           // its value once every boundary workgroup launched so far has finished
+    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_int = nullptr;
+    unsigned* edge_counter = nullptr;   // device word the boundary workgroups of a pass count themselves into (z-slabs)
+    unsigned* edge_signal = nullptr;    // signal memory: the count, published by the workgroup that completes a pass's share
+    unsigned edge_target = 0;           // the count once every boundary workgroup launched so far has finished
     static constexpr int NRED = 3 * 1024 + 3;
 
     explicit Engine(fs_sim* s) : S(s) {}
@@ -263,14 +265,20 @@ struct Engine : EngineBase {
             HIP_TRY(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, hi_pri));
             HIP_TRY(hipEventCreateWithFlags(&ev_edges, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ev_int, hipEventDisableTiming));
             // stream-side wait on a memory word (hipStreamWaitValue32): where the device offers it, a pass computes its
             // boundary planes in the leading workgroups of the interior launch
             int can_wait = 0;
             if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, S->device) == hipSuccess && can_wait &&
-                hipExtMallocWithFlags((void**)&edge_counter, 8, hipMallocSignalMemory) == hipSuccess) {
-                if (hipMemset(edge_counter, 0, 8) != hipSuccess) { hipFree(edge_counter); edge_counter = nullptr; }
+                hipExtMallocWithFlags((void**)&edge_signal, 8, hipMallocSignalMemory) == hipSuccess &&
+                hipMalloc((void**)&edge_counter, 4) == hipSuccess && hipMemset(edge_counter, 0, 4) == hipSuccess &&
+                hipMemset(edge_signal, 0, 8) == hipSuccess) {
+                // ready
             } else {
-                edge_counter = nullptr;
+                if (edge_signal) hipFree(edge_signal);
+                if (edge_counter) hipFree(edge_counter);
+        if (edge_signal) hipFree(edge_signal);
+                edge_signal = edge_counter = nullptr;
                 (void)hipGetLastError();
             }
         }
@@ -290,8 +298,10 @@ struct Engine : EngineBase {
         if (red) hipFree(red);
         if (coltab) hipFree(coltab);
         if (edge_counter) hipFree(edge_counter);
+        if (edge_signal) hipFree(edge_signal);
         if (ev_edges) hipEventDestroy(ev_edges);
         if (ev_halo) hipEventDestroy(ev_halo);
+        if (ev_int) hipEventDestroy(ev_int);
         if (comm_stream) hipStreamDestroy(comm_stream);
     }
 
@@ -469,7 +479,27 @@ struct Engine : EngineBase {
                 // planes a neighbour needs of this pass's result: as many as its next pass has levels; after
                 // the last pass the halos are brought to their full depth (what every other kernel assumes)
                 const int e = (i + 1 < npass) ? plan[i + 1] : g.zh;
-                if (S->overlap && g.D >= 2 * e + 8) {
+                if (S->overlap == 2 && g.D >= 2 * e + 8) {
+                    // Two streams: the boundary regions of pass k and its interior only depend on pass k-1, not on each
+                    // other, so they are queued side by side -- boundary launch + exchange on the high-priority
+                    // communication stream, interior on the compute stream -- and the hardware overlaps them.
+                    const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
+                    if (i > 0) HIP_TRY(hipStreamWaitEvent(S->stream, ev_edges, 0));      // interior k reads (and overwrites what) boundary k-1 (read)
+                    else HIP_TRY(hipEventRecord(ev_int, S->stream));                       // first pass: everything queued so far
+                    HIP_TRY(hipStreamWaitEvent(comm_stream, ev_int, 0));                   // boundary k reads interior k-1
+                    if (!sc.lo_wall && !sc.hi_wall) launch_pass(comm_stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e, g.D - e + 1);
+                    else if (!sc.lo_wall) launch_pass(comm_stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e);
+                    else if (!sc.hi_wall) launch_pass(comm_stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, g.D - e + 1, g.D);
+                    HIP_TRY(hipEventRecord(ev_edges, comm_stream));
+                    launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, in_lo, in_hi);
+                    HIP_TRY(hipEventRecord(ev_int, S->stream));
+                    if (S->comm.exchange_halo(comm_stream, arr[dst], g, sizeof(T), S->D, e))
+                        return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
+                    if (i + 1 == npass) {                 // whoever reads the result next runs on the compute stream
+                        HIP_TRY(hipEventRecord(ev_halo, comm_stream));
+                        HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
+                    }
+                } else if (S->overlap && g.D >= 2 * e + 8) {
                     // Boundary planes first (both regions in one launch); their exchange then travels on
                     // the high-priority communication stream while the interior planes are computed
                     // (SURVEY 8e).  Running the boundary launch concurrently with the interior one on a
@@ -485,14 +515,17 @@ struct Engine : EngineBase {
                         ef.first = sc.lo_wall ? g.D - e + 1 : 1;
                         ef.second = (!sc.lo_wall && !sc.hi_wall) ? g.D - e + 1 : -1;
                         ef.counter = edge_counter;
+                        ef.signal = edge_signal;
                         if (edge_target > 0x7f000000u) {     // keep the 32-bit count far from wrapping: drain and restart it
                             HIP_TRY(hipStreamSynchronize(S->stream));
                             HIP_TRY(hipStreamSynchronize(comm_stream));
-                            HIP_TRY(hipMemset(edge_counter, 0, 8));
+                            HIP_TRY(hipMemset(edge_counter, 0, 4));
+                            HIP_TRY(hipMemset(edge_signal, 0, 8));
                             edge_target = 0;
                         }
+                        ef.done_before = edge_target;
                         edge_target += (unsigned)launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, in_lo, in_hi, -1, &ef);
-                        HIP_TRY(hipStreamWaitValue32(comm_stream, edge_counter, edge_target, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                        HIP_TRY(hipStreamWaitValue32(comm_stream, edge_signal, edge_target, hipStreamWaitValueGte, 0xFFFFFFFFu));
                     } else {
                         if (!sc.lo_wall && !sc.hi_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e, g.D - e + 1);
                         else if (!sc.lo_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e);
@@ -1321,7 +1354,8 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
     } else if (k == "fuse_advect") {
         s->fuse_advect = (v != "0");
     } else if (k == "overlap") {
-        s->overlap = (v != "0");
+        s->overlap = atoi(value);
+        if (s->overlap < 0 || s->overlap > 2) return fail(FS_EINVAL, "overlap: 0 | 1 | 2");
     } else if (k == "edge_merge") {
         s->edge_merge = (v != "0");
     } else if (k == "debug_poison_gather") {

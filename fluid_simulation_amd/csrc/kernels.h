@@ -58,12 +58,14 @@ struct SweepTune {
 // Boundary-first launch of a z-slab pass in ONE grid: the first workgroups of the grid (lowest block ids, dispatched
 // first) compute the slab's boundary regions -- planes first..first+planes-1 and, with second >= 0, second..second+
 // planes-1 -- and each adds 1 to *counter (agent scope, after its stores have been written back to memory) when it is
-// done; the rest of the grid computes the launch's own plane range.  A stream can then wait for the counter
-// (hipStreamWaitValue32) and start the halo exchange while the interior is still being computed.  The launchers return
-// how many workgroups will signal.
+// done; the one that completes the launch's count writes it to *signal; the rest of the grid computes the launch's own
+// plane range.  A stream can then wait for the signal word (hipStreamWaitValue32 >= done_before + returned count) and
+// start the halo exchange while the interior is still being computed.  The launchers return how many workgroups count.
 struct EdgeFirst {
     int first = 0, second = -1, planes = 0;
-    unsigned* counter = nullptr;
+    unsigned* counter = nullptr;   // device memory, counts finished boundary workgroups over all launches
+    unsigned* signal = nullptr;    // signal memory (hipMallocSignalMemory): receives the count when a launch's last one finishes
+    unsigned done_before = 0;      // value of *counter once everything launched BEFORE this launch has finished
 };
 
 // NOTE: the sweep launchers take the KILL-byte array (launch_build_kill), not the flag bytes.

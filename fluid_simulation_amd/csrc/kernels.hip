@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
         xm = xc;
         xc = xn;
     }
-    if (edge_block) edge_signal(ea.counter);
+    if (edge_block) edge_signal(ea);
 }
 
 template <class T, int NXW, int NYW>
@@ -526,14 +526,15 @@ static int launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc& 
     const int planes = z_last - z_first + 1;
     if (planes <= 0) return 0;
     const int nbands = (g.H + (BY - 2) - 1) / (BY - 2);
-    EdgeArgs ea = {0, 0, -1, 0, nullptr};
+    EdgeArgs ea = {0, 0, -1, 0, nullptr, nullptr, 0u};
     if (edges && edges->counter && edges->planes > 0)
-        ea = EdgeArgs{nbands * (edges->second >= 0 ? 2 : 1), edges->first, edges->second, edges->planes, edges->counter};
+        ea = EdgeArgs{nbands * (edges->second >= 0 ? 2 : 1), edges->first, edges->second, edges->planes, edges->counter, edges->signal,
+                      edges->done_before + (unsigned)(nbands * (edges->second >= 0 ? 2 : 1))};
     if (second_first >= 0) {
         // two equally long ranges (the slab's two boundary regions) as two chunks of one launch
         hipLaunchKernelGGL(kernel, dim3(nbands * 2), dim3(NXW * NYW * 64), 0, st, g, sc, src,
                            rhs, dst, flags, b, a, inv_c, z_first, second_first + planes - 1, planes,
-                           second_first - z_first, nbands, nbands * 2, omega, EdgeArgs{0, 0, -1, 0, nullptr});
+                           second_first - z_first, nbands, nbands * 2, omega, EdgeArgs{0, 0, -1, 0, nullptr, nullptr, 0u});
         return 0;
     }
     // z chunks: each re-reads 4 level-0 planes and recomputes 2 level-1 planes, so keep them

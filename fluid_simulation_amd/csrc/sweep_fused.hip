@@ -385,7 +385,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         iter(IC<2>{}, zl);
         if (++zl > zl_end) break;
     }
-    if (edge_block) edge_signal(ea.counter);
+    if (edge_block) edge_signal(ea);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -409,9 +409,10 @@ static int launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc&
     if (planes <= 0) return 0;
     const int nbands = fused_bands<NL>(g.H, BY);
     const bool aligned = (g.W == NXW * 256);
-    EdgeArgs ea = {0, 0, -1, 0, nullptr};
+    EdgeArgs ea = {0, 0, -1, 0, nullptr, nullptr, 0u};
     if (edges && edges->counter && edges->planes > 0 && second_first < 0)
-        ea = EdgeArgs{nbands * (edges->second >= 0 ? 2 : 1), edges->first, edges->second, edges->planes, edges->counter};
+        ea = EdgeArgs{nbands * (edges->second >= 0 ? 2 : 1), edges->first, edges->second, edges->planes, edges->counter, edges->signal,
+                      edges->done_before + (unsigned)(nbands * (edges->second >= 0 ? 2 : 1))};
     const bool whole = sc.lo_wall && sc.hi_wall && z_first == 1 && z_last == g.D && second_first < 0 && ea.nblocks == 0;
     int zc_len, z_stride, nblk;
     if (second_first >= 0) {

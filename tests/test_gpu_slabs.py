@@ -30,8 +30,8 @@ def run_ranks(tmp, nranks, args):
     return out
 
 
-@pytest.mark.parametrize("nranks,D,opts", [(2, 16, ""), (4, 16, ""), (2, 32, ""), (3, 48, ""), (2, 32, "edge_merge=0"),
-                                            (3, 48, "edge_merge=0"), (2, 32, "overlap=0")])
+@pytest.mark.parametrize("nranks,D,opts", [(2, 16, ""), (4, 16, ""), (2, 32, ""), (3, 48, ""), (2, 32, "edge_merge=1"),
+                                            (3, 48, "edge_merge=1"), (2, 32, "overlap=0"), (2, 32, "overlap=2"), (3, 48, "overlap=2")])
 def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D, opts):
     # local depth 16 (D=32 and D=48 cases) is deep enough for the boundary-first schedule that overlaps the
     # halo exchange with interior compute -- by default with the boundary planes computed in the leading
@@ -57,7 +57,7 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D, opts):
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (r, k, "halo")
         if r == 0:
             print("edge_merge_active:", int(z["kernels"][3]), "(hipStreamWaitValue32 path)" if int(z["kernels"][3]) else "(separate boundary launch)")
-        if "edge_merge=0" in opts:
+        if "edge_merge=1" not in opts:
             assert int(z["kernels"][3]) == 0
         # the advection source was fetched through the velocity-bounded window (poisoned outside)
         assert 2 <= int(z["reach"]) < D

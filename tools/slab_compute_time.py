@@ -17,7 +17,7 @@ rank = int(sys.argv[5]) if len(sys.argv) > 5 else P // 2
 acc = int(sys.argv[6]) if len(sys.argv) > 6 else 80
 steps = int(sys.argv[7]) if len(sys.argv) > 7 else 3
 out = {"grid": [W, H, D], "ranks": P, "rank": rank, "acc": acc}
-for overlap, merge in ((1, 1), (1, 0), (0, 0)):
+for overlap, merge in ((2, 0), (1, 1), (1, 0), (0, 0)):
     sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0, profile=1, overlap=overlap, edge_merge=merge)
     if P > 1:
         sim.comm_init(rank, P, b"FSNULL:".ljust(128, b"\0"))
