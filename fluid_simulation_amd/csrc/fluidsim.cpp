@@ -84,6 +84,7 @@ struct EngineBase {
     virtual int edge_merge_available() const = 0;
     virtual int streamlines(int density, double proximity, int max_length, double step_size, double threshold) = 0;
     virtual int obstacle_surface() = 0;
+    virtual int reference_order_sum(int which, double* out) = 0;
 };
 
 struct fs_sim {
@@ -1127,6 +1128,28 @@ struct Engine : EngineBase {
 
     int stats(int which, double* out3) override { return stats_of(arr[slot[which]], out3); }
 
+    // The number Simulation::run() prints every 100 steps: std::reduce(dens.begin(), dens.end()) (simulation.cpp:76),
+    // i.e. a sum in the field's own precision in libstdc++'s order -- groups of four as (a0 + a1) + (a2 + a3), added to the
+    // running sum one group at a time (<numeric>, random-access branch).  A rounding chain cannot be reordered, so the
+    // dense array comes to the host for it (once per 100 steps, console output only).
+    int reference_order_sum(int which, double* out) override
+    {
+        const long n = dense_cells();
+        std::vector<T> h((size_t)n);
+        int rc = get_field(which, h.data(), (size_t)n, (int)sizeof(T));
+        if (rc) return rc;
+        T init = (T)0;
+        long i = 0;
+        for (; n - i >= 4; i += 4) {
+            const T v1 = h[i] + h[i + 1], v2 = h[i + 2] + h[i + 3];
+            const T v3 = v1 + v2;
+            init = init + v3;
+        }
+        for (; i < n; ++i) init = init + h[i];
+        *out = (double)init;
+        return FS_OK;
+    }
+
     int stats_of(const T* field, double* out3)
     {
         // whole padded array (simulation.cpp:76, :82-89); a slab counts its own planes plus
@@ -1527,8 +1550,11 @@ int fs_run(fs_sim* s)
     for (int i = 0; i < s->iter && !rc; ++i) {
         rc = s->eng->run_one();
         if (!rc && (i + 1) % 100 == 0 && i > 0) {         // :73-77
-            double st[3];
-            rc = s->eng->stats(FS_DENS, st);
+            // one GPU: the reference's own float sum, digit for digit; z-slabs: the all-reduced double sum (a rounding
+            // chain over the whole array does not split over ranks)
+            double st[3] = {0, 0, 0};
+            if (s->comm.active()) rc = s->eng->stats(FS_DENS, st);
+            else if (talk) rc = s->eng->reference_order_sum(FS_DENS, &st[0]);
             if (!rc && talk) printf("step %d\n  density sum = %g\n", i + 1, st[0]);
         }
     }

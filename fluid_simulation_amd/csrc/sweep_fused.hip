@@ -50,6 +50,14 @@ struct IC {
     static constexpr int value = N;
 };
 
+// Experiment switch (build with -DFS_EXP_NT=1|2|3): nontemporal loads of the right-hand side (1) and / or nontemporal
+// stores of the result (2).  See DESIGN.md section 4 for what was measured; the shipped library is built with 0.
+#ifndef FS_EXP_NT
+#define FS_EXP_NT 0
+#endif
+template <class T>
+using Vec4 = T __attribute__((ext_vector_type(4)));
+
 template <class T, int NL, int NXW, int NYW, int RY, bool ALIGNED, bool SLAB>
 __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                                       const T* __restrict__ rhs, T* __restrict__ dst,
@@ -73,6 +81,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     // row pointers and every row test then live in scalar registers and branch as scalars
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wx = wave % NXW, wy = wave / NXW;
+    if ((FS_EXP_NT & 4) && wave >= (NXW * NYW) / 2) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
     const int W = g.W, H = g.H, D = g.D;
     const int s = band * (BY - 2 * OV);                  // tile row t <-> grid row s + t
     const int ty0 = wy * RY, y0 = s + ty0;
@@ -141,7 +150,11 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         for (int r = 0; r < RY; ++r) {
             eL[r] = *reinterpret_cast<const T*>(sp + oc[r] - ES);        // every lane fetches its own x neighbours:
             eR[r] = *reinterpret_cast<const T*>(sp + oc[r] + 4 * ES);    // no shuffles, no edge lanes
-            ld4(rp + oc[r], rcur[r]);
+            if (FS_EXP_NT & 1) {
+                const Vec4<T> q = __builtin_nontemporal_load(reinterpret_cast<const Vec4<T>*>(rp + oc[r]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rcur[r][e] = q[e];
+            } else ld4(rp + oc[r], rcur[r]);
             flc[r] = (unsigned)fp[(oc[r] / (unsigned)ES + 3u) >> 2];
         }
     };
@@ -235,10 +248,17 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         T st[4];
         settle4(u, fl, st);
         char* base = reinterpret_cast<char*>(dst) + (long)zo * plane_b + oc[r];
-        V4<T> q;
+        if (FS_EXP_NT & 2) {
+            Vec4<T> q;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q.e[e] = st[e];
-        *reinterpret_cast<V4<T>*>(base) = q;
+            for (int e = 0; e < 4; ++e) q[e] = st[e];
+            __builtin_nontemporal_store(q, reinterpret_cast<Vec4<T>*>(base));
+        } else {
+            V4<T> q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q.e[e] = st[e];
+            *reinterpret_cast<V4<T>*>(base) = q;
+        }
         if (x0 == 1) *reinterpret_cast<T*>(base - ES) = (b == 1) ? -u[0] : u[0];                    // :189-190
         if (full_group && x0 + 3 == W) *reinterpret_cast<T*>(base + 4 * ES) = u[3];                // :191
         if (y == 1 || y == H) {

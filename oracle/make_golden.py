@@ -191,6 +191,7 @@ def main():
     g3_voxelizer()
     g4_layout()
     g5_stock_run()
+    g6_stock_run_console()
     manifest = dict(
         compiler=subprocess.check_output(["g++", "--version"]).decode().splitlines()[0],
         flags="-std=c++20 -O2 -fopenmp -fPIC (reference Makefile:5 + -fPIC)",
@@ -236,5 +237,29 @@ def g5_stock_run():
     print("wrote g5_stock_run_digests.json")
 
 
+def g6_stock_run_console():
+    """What the reference program prints during that same default run (simulation.cpp:51-53, 73-77, 81-90):
+    the `density sum` line is std::reduce over floats in libstdc++'s order, the min / max lines are exact.
+    Text fixture: the program's OUTPUT, one thread."""
+    W, H, D, steps, acc = 128, 64, 64, 100, 15
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from oracle import cpu_ref as O\n"
+        "r = O.Reference(%d, %d, %d, iter=%d, acc=%d)\n"
+        "r.run()\n" % (ROOT, W, H, D, steps, acc))
+    with tempfile.TemporaryDirectory() as tmp:
+        os.mkdir(os.path.join(tmp, "data"))
+        out = subprocess.run([sys.executable, "-c", code], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    with open(os.path.join(OUT, "g6_stock_run_stdout.txt"), "wb") as f:
+        f.write(out.stdout)
+    print("wrote g6_stock_run_stdout.txt (%d bytes)" % len(out.stdout))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g6":      # add the console fixture without regenerating the others
+        if os.environ.get("OMP_NUM_THREADS") != "1":
+            sys.exit("run with OMP_NUM_THREADS=1")
+        O.build()
+        g6_stock_run_console()
+    else:
+        main()

@@ -422,9 +422,13 @@ def test_stock_run_of_the_reference_program_byte_identical(tmp_path):
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", ROOT, "simulation.out"])
     (tmp_path / "data").mkdir()
-    out = subprocess.run([exe, "--solver", "gs_lex", "--quiet"], cwd=str(tmp_path), capture_output=True, text=True,
-                         timeout=900)
+    out = subprocess.run([exe, "--solver", "gs_lex"], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
+    # ... and the console says what the reference's console said (tests/golden/g6_stock_run_stdout.txt, recorded from
+    # the compiled reference at one thread): the density sum is std::reduce over floats in libstdc++'s order
+    # (simulation.cpp:73-77), the min / max lines are exact (:81-90)
+    want = open(os.path.join(GOLDEN, "g6_stock_run_stdout.txt")).read()
+    assert out.stdout.strip().splitlines() == want.strip().splitlines()
     for fn, want in meta["files"].items():
         h = hashlib.sha256()
         with open(str(tmp_path / "data" / (fn + ".bin")), "rb") as f:
