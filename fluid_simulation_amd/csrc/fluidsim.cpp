@@ -81,7 +81,6 @@ struct EngineBase {
     virtual int tuned_shape() const = 0;
     virtual int tuned_triple() const = 0;
     virtual int halo_depth() const = 0;
-    virtual int edge_merge_available() const = 0;
     virtual int streamlines(int density, double proximity, int max_length, double step_size, double threshold) = 0;
     virtual int obstacle_surface() = 0;
     virtual int reference_order_sum(int which, double* out) = 0;
@@ -102,7 +101,6 @@ struct fs_sim {
     bool fuse_advect = true;     // one kernel for the three velocity advections of a step (single GPU)
     int overlap = 1;             // z-slabs: exchange boundary planes while the interior is computed (1: boundary launch, then
                                  // interior launch, one stream; 2: boundary + exchange on the communication stream beside the interior)
-    bool edge_merge = false;      // ... with the boundary planes computed by the leading workgroups of the interior launch
     bool debug_poison = false;   // fill the gathered advection source with NaN bit patterns before each gather
     int last_reach = 0;          // planes of reach used by the most recent slab advection
     // device
@@ -206,9 +204,6 @@ struct Engine : EngineBase {
     int triple_alt = -1;                // >= 0: three sweeps per pass beat two on this grid (launch plan id)
     hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
     hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_int = nullptr;
-    unsigned* edge_counter = nullptr;   // device word the boundary workgroups of a pass count themselves into (z-slabs)
-    unsigned* edge_signal = nullptr;    // signal memory: the count, published by the workgroup that completes a pass's share
-    unsigned edge_target = 0;           // the count once every boundary workgroup launched so far has finished
     static constexpr int NRED = 3 * 1024 + 3;
 
     explicit Engine(fs_sim* s) : S(s) {}
@@ -267,21 +262,6 @@ struct Engine : EngineBase {
             HIP_TRY(hipEventCreateWithFlags(&ev_edges, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ev_int, hipEventDisableTiming));
-            // stream-side wait on a memory word (hipStreamWaitValue32): where the device offers it, a pass computes its
-            // boundary planes in the leading workgroups of the interior launch
-            int can_wait = 0;
-            if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, S->device) == hipSuccess && can_wait &&
-                hipExtMallocWithFlags((void**)&edge_signal, 8, hipMallocSignalMemory) == hipSuccess &&
-                hipMalloc((void**)&edge_counter, 4) == hipSuccess && hipMemset(edge_counter, 0, 4) == hipSuccess &&
-                hipMemset(edge_signal, 0, 8) == hipSuccess) {
-                // ready
-            } else {
-                if (edge_signal) hipFree(edge_signal);
-                if (edge_counter) hipFree(edge_counter);
-        if (edge_signal) hipFree(edge_signal);
-                edge_signal = edge_counter = nullptr;
-                (void)hipGetLastError();
-            }
         }
         return FS_OK;
     }
@@ -298,8 +278,6 @@ struct Engine : EngineBase {
         if (dense) hipFree(dense);
         if (red) hipFree(red);
         if (coltab) hipFree(coltab);
-        if (edge_counter) hipFree(edge_counter);
-        if (edge_signal) hipFree(edge_signal);
         if (ev_edges) hipEventDestroy(ev_edges);
         if (ev_halo) hipEventDestroy(ev_halo);
         if (ev_int) hipEventDestroy(ev_int);
@@ -385,20 +363,18 @@ struct Engine : EngineBase {
     // ---- linearSolver (simulation.cpp:251-273) -----------------------------------------
     // One pass over memory that applies `levels` (1, 2 or 3) Jacobi sweeps to planes zf..zl (and, with
     // second >= 0, to the equally long range starting there).
-    // `edges`: also compute the slab's boundary regions, in the leading workgroups of the same grid (two- and
-    // three-sweep kernels only); returns how many workgroups will count themselves into edges->counter.
-    int launch_pass(hipStream_t st, int levels, bool rb, const T* src_, const T* rhs_, T* dst_, int b, T a, T inv_c, int zf,
-                    int zl, int second = -1, const fs::EdgeFirst* edges = nullptr)
+    void launch_pass(hipStream_t st, int levels, bool rb, const T* src_, const T* rhs_, T* dst_, int b, T a, T inv_c, int zf,
+                     int zl, int second = -1)
     {
         const T omega = rb ? (T)S->omega : (T)0;
         if (levels == 3)
-            return fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 3, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, triple_alt, second, edges);
-        if (levels == 2 && !rb && pair_shape >= FUSED2)
-            return fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 2, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape - FUSED2, second, edges);
-        if (levels == 2)
-            return fs::launch_jacobi_pair<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape, second, omega, edges);
-        fs::launch_jacobi<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, second);
-        return 0;
+            fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 3, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, triple_alt, second);
+        else if (levels == 2 && !rb && pair_shape >= FUSED2)
+            fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 2, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape - FUSED2, second);
+        else if (levels == 2)
+            fs::launch_jacobi_pair<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape, second, omega);
+        else
+            fs::launch_jacobi<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, second);
     }
     bool two_sweep_kernels() const
     {
@@ -503,38 +479,16 @@ struct Engine : EngineBase {
                 } else if (S->overlap && g.D >= 2 * e + 8) {
                     // Boundary planes first (both regions in one launch); their exchange then travels on
                     // the high-priority communication stream while the interior planes are computed
-                    // (SURVEY 8e).  Running the boundary launch concurrently with the interior one on a
-                    // second stream was measured slower: the interior workgroups fill every CU.
+                    // (SURVEY 8e).  Measured alternatives, both slower: the boundary launch on the
+                    // communication stream beside the interior launch (overlap=2 above), and one launch whose leading
+                    // workgroups are the boundary planes with the exchange released by hipStreamWaitValue32.
                     const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
-                    if (edge_counter && lv >= 2 && S->edge_merge) {
-                        // ... as the leading workgroups of the SAME launch as the interior: the boundary workgroups
-                        // count themselves into a signal word when their planes are in memory, and the communication
-                        // stream waits for that count instead of for a separate 20 us launch (which left most of the
-                        // chip idle 240 times per step)
-                        fs::EdgeFirst ef;
-                        ef.planes = e;
-                        ef.first = sc.lo_wall ? g.D - e + 1 : 1;
-                        ef.second = (!sc.lo_wall && !sc.hi_wall) ? g.D - e + 1 : -1;
-                        ef.counter = edge_counter;
-                        ef.signal = edge_signal;
-                        if (edge_target > 0x7f000000u) {     // keep the 32-bit count far from wrapping: drain and restart it
-                            HIP_TRY(hipStreamSynchronize(S->stream));
-                            HIP_TRY(hipStreamSynchronize(comm_stream));
-                            HIP_TRY(hipMemset(edge_counter, 0, 4));
-                            HIP_TRY(hipMemset(edge_signal, 0, 8));
-                            edge_target = 0;
-                        }
-                        ef.done_before = edge_target;
-                        edge_target += (unsigned)launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, in_lo, in_hi, -1, &ef);
-                        HIP_TRY(hipStreamWaitValue32(comm_stream, edge_signal, edge_target, hipStreamWaitValueGte, 0xFFFFFFFFu));
-                    } else {
-                        if (!sc.lo_wall && !sc.hi_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e, g.D - e + 1);
-                        else if (!sc.lo_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e);
-                        else if (!sc.hi_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, g.D - e + 1, g.D);
-                        HIP_TRY(hipEventRecord(ev_edges, S->stream));
-                        launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, in_lo, in_hi);
-                        HIP_TRY(hipStreamWaitEvent(comm_stream, ev_edges, 0));
-                    }
+                    if (!sc.lo_wall && !sc.hi_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e, g.D - e + 1);
+                    else if (!sc.lo_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e);
+                    else if (!sc.hi_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, g.D - e + 1, g.D);
+                    HIP_TRY(hipEventRecord(ev_edges, S->stream));
+                    launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, in_lo, in_hi);
+                    HIP_TRY(hipStreamWaitEvent(comm_stream, ev_edges, 0));
                     if (S->comm.exchange_halo(comm_stream, arr[dst], g, sizeof(T), S->D, e))
                         return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
                     HIP_TRY(hipEventRecord(ev_halo, comm_stream));
@@ -957,7 +911,6 @@ struct Engine : EngineBase {
 
     int tuned_shape() const override { return pair_shape; }
     int halo_depth() const override { return g.zh; }
-    int edge_merge_available() const override { return edge_counter != nullptr; }
     int tuned_triple() const override { return triple_alt; }
 
     // ---- the viewer's streamlines (GUI/utils.py:118-213) -------------------------------------
@@ -1379,8 +1332,6 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
     } else if (k == "overlap") {
         s->overlap = atoi(value);
         if (s->overlap < 0 || s->overlap > 2) return fail(FS_EINVAL, "overlap: 0 | 1 | 2");
-    } else if (k == "edge_merge") {
-        s->edge_merge = (v != "0");
     } else if (k == "debug_poison_gather") {
         s->debug_poison = (v != "0");
     } else if (k == "sweep_ry") {
@@ -1433,7 +1384,6 @@ int fs_get_int(fs_sim* s, const char* name, int* out)
     else if (n == "triple_plan") *out = s->eng ? s->eng->tuned_triple() : -1;
     else if (n == "two_sweep_fused") *out = (s->eng && s->eng->tuned_shape() >= 64) ? 1 : 0;   // 1: jacobi_fused_kernel<NL=2>, 0: jacobi_pair_kernel
     else if (n == "halo_depth") *out = s->eng ? s->eng->halo_depth() : 0;
-    else if (n == "edge_merge_active") *out = (s->eng && s->edge_merge) ? s->eng->edge_merge_available() : 0;
     else return fail(FS_EINVAL, "unknown int member '%s'", name);
     return FS_OK;
 }

@@ -55,19 +55,6 @@ struct SweepTune {
     int two_kind = 0;         // which two-sweep kernel: 0 = timed choice, 1 = jacobi_pair_kernel only, 2 = jacobi_fused_kernel<NL=2> only
 };
 
-// Boundary-first launch of a z-slab pass in ONE grid: the first workgroups of the grid (lowest block ids, dispatched
-// first) compute the slab's boundary regions -- planes first..first+planes-1 and, with second >= 0, second..second+
-// planes-1 -- and each adds 1 to *counter (agent scope, after its stores have been written back to memory) when it is
-// done; the one that completes the launch's count writes it to *signal; the rest of the grid computes the launch's own
-// plane range.  A stream can then wait for the signal word (hipStreamWaitValue32 >= done_before + returned count) and
-// start the halo exchange while the interior is still being computed.  The launchers return how many workgroups count.
-struct EdgeFirst {
-    int first = 0, second = -1, planes = 0;
-    unsigned* counter = nullptr;   // device memory, counts finished boundary workgroups over all launches
-    unsigned* signal = nullptr;    // signal memory (hipMallocSignalMemory): receives the count when a launch's last one finishes
-    unsigned done_before = 0;      // value of *counter once everything launched BEFORE this launch has finished
-};
-
 // NOTE: the sweep launchers take the KILL-byte array (launch_build_kill), not the flag bytes.
 template <class T>
 void launch_jacobi(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
@@ -81,10 +68,9 @@ void launch_jacobi(hipStream_t st, const SweepTune& tune, const GridDesc& g, con
 template <class T>
 bool pair_supported(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc);
 template <class T>
-int launch_jacobi_pair(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
-                       T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
-                       int second_first = -1, T omega = (T)0,   // omega != 0: one red-black SOR iteration instead
-                       const EdgeFirst* edges = nullptr);
+void launch_jacobi_pair(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
+                        T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
+                        int second_first = -1, T omega = (T)0);   // omega != 0: one red-black SOR iteration instead
 // NL = `levels` (2 or 3) sweeps per pass, register-centred (sweep_fused.hip): fp32 x 3 for rows up to 512
 // cells, fp32 x 2 for rows of 513..1024 cells, fp64 x 2 for rows up to 512 cells.  On a z-slab `src` needs
 // `levels` current halo planes per side, `rhs` and `flags` levels-1.  plan = workgroup shape
@@ -94,9 +80,9 @@ bool fused_supported(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc
 template <class T>
 int fused_shape_count(const GridDesc& g, int levels);
 template <class T>
-int launch_jacobi_fused(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int levels, const T* src,
-                        const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int plan,
-                        int second_first = -1, const EdgeFirst* edges = nullptr);
+void launch_jacobi_fused(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int levels, const T* src,
+                         const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int plan,
+                         int second_first = -1);
 // number of workgroup shapes (0 .. count-1) worth timing for this grid; results do not depend on the shape
 template <class T>
 int pair_shape_count(const GridDesc& g);

@@ -267,16 +267,13 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
                                                                      const T* __restrict__ rhs, T* __restrict__ dst,
                                                                      const uint8_t* __restrict__ flags, int b, T a,
                                                                      T inv_c, int z_first, int z_last, int zc_len,
-                                                                     int z_stride, int nbands, int nblk, T omega, EdgeArgs ea)
+                                                                     int z_stride, int nbands, int nblk, T omega)
 {
     constexpr int RY = 2, BY = NYW * RY, TW = NXW * 256 + 8;
     // ring of four level-1 plane tiles (plane z lives in slot z & 3); column index = x + 3
     __shared__ T tile[4][BY][TW];
 
-    // the leading ea.nblocks workgroups compute a slab's boundary regions (EdgeFirst, kernels.h), the others the chunks
-    // of z_first..z_last
-    const bool edge_block = (int)blockIdx.x < ea.nblocks;
-    const int v = edge_block ? (int)blockIdx.x : xcd_contiguous((int)blockIdx.x - ea.nblocks, nblk);
+    const int v = xcd_contiguous(blockIdx.x, nblk);
     const int band = v % nbands, zc = v / nbands;
     // readfirstlane: the wave index is the same in all 64 lanes, but only this tells the compiler so -- rows,
     // row pointers and every row test then live in scalar registers and branch as scalars
@@ -287,9 +284,8 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
     const int ty0 = wy * RY, y0 = s + ty0;
     const int x0 = 1 + wx * 256 + lane * 4;
     const bool lane_on = x0 <= W;
-    const int zbeg = edge_block ? (zc ? ea.second : ea.first) : z_first + zc * z_stride;          // level-2 output planes
-    const int zend = edge_block ? zbeg + ea.planes - 1 : min(z_last, zbeg + zc_len - 1);
-    if (zbeg > zend) return;                             // block-uniform (never a boundary workgroup)
+    const int zbeg = z_first + zc * z_stride, zend = min(z_last, zbeg + zc_len - 1);  // level-2 output planes
+    if (zbeg > zend) return;                             // block-uniform
     // level-1 planes: one beyond the output chunk on each side; beyond a physical wall there is
     // no such plane (its level-1 ghost is derived below), beyond a slab boundary it is the
     // neighbour's plane, recomputed here from the two-deep halo
@@ -512,30 +508,25 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
         xm = xc;
         xc = xn;
     }
-    if (edge_block) edge_signal(ea);
 }
 
 template <class T, int NXW, int NYW>
-static int launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
+static void launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
                           const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt,
-                          int second_first, T omega, const EdgeFirst* edges)
+                          int second_first, T omega)
 {
     // omega == 0: two Jacobi sweeps; otherwise one red-black SOR iteration with that relaxation factor
     auto kernel = (omega != (T)0) ? jacobi_pair_kernel<T, NXW, NYW, true> : jacobi_pair_kernel<T, NXW, NYW, false>;
     constexpr int BY = NYW * 2;
     const int planes = z_last - z_first + 1;
-    if (planes <= 0) return 0;
+    if (planes <= 0) return;
     const int nbands = (g.H + (BY - 2) - 1) / (BY - 2);
-    EdgeArgs ea = {0, 0, -1, 0, nullptr, nullptr, 0u};
-    if (edges && edges->counter && edges->planes > 0)
-        ea = EdgeArgs{nbands * (edges->second >= 0 ? 2 : 1), edges->first, edges->second, edges->planes, edges->counter, edges->signal,
-                      edges->done_before + (unsigned)(nbands * (edges->second >= 0 ? 2 : 1))};
     if (second_first >= 0) {
         // two equally long ranges (the slab's two boundary regions) as two chunks of one launch
         hipLaunchKernelGGL(kernel, dim3(nbands * 2), dim3(NXW * NYW * 64), 0, st, g, sc, src,
                            rhs, dst, flags, b, a, inv_c, z_first, second_first + planes - 1, planes,
-                           second_first - z_first, nbands, nbands * 2, omega, EdgeArgs{0, 0, -1, 0, nullptr, nullptr, 0u});
-        return 0;
+                           second_first - z_first, nbands, nbands * 2, omega);
+        return;
     }
     // z chunks: each re-reads 4 level-0 planes and recomputes 2 level-1 planes, so keep them
     // long; pick the count that fills the CUs most evenly (one workgroup per CU)
@@ -565,9 +556,8 @@ static int launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc& 
     if (tune.pair_zc > 0) zc_len = tune.pair_zc < planes ? tune.pair_zc : planes;
     const int nzc = (planes + zc_len - 1) / zc_len;
     const int nblk = nbands * nzc;
-    hipLaunchKernelGGL(kernel, dim3(nblk + ea.nblocks), dim3(NXW * NYW * 64), 0, st, g, sc, src, rhs,
-                       dst, flags, b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk, omega, ea);
-    return ea.nblocks;
+    hipLaunchKernelGGL(kernel, dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, sc, src, rhs,
+                       dst, flags, b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk, omega);
 }
 
 template <class T>
@@ -585,9 +575,9 @@ template <>
 int pair_shape_count<double>(const GridDesc&) { return 1; }
 
 template <>
-int launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const float* src,
-                              const float* rhs, float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first,
-                              int z_last, int shape, int second_first, float omega, const EdgeFirst* edges)
+void launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const float* src,
+                               const float* rhs, float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first,
+                               int z_last, int shape, int second_first, float omega)
 {
     // shape: 0 = 12 waves (768 threads, <=168 VGPRs), 2 = 10 waves, 1 = 8 waves, 3 = 16 waves (spills;
     // tuning tool only).  All shapes give identical results; the host driver times 0..count-1 once per
@@ -597,7 +587,7 @@ int launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const GridD
     const int alt = shape >> 3;                          // which of the three best chunk counts
     shape &= 7;
     if (tune.pair_shape > 0) shape = tune.pair_shape;
-#define FS_PAIR(NX, NY) return launch_pair_v<float, NX, NY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, edges)
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 2) FS_PAIR(1, 10); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 2) FS_PAIR(2, 5); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
@@ -605,16 +595,16 @@ int launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const GridD
 #undef FS_PAIR
 }
 template <>
-int launch_jacobi_pair<double>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const double* src,
-                               const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
-                               int z_first, int z_last, int shape, int second_first, double omega, const EdgeFirst* edges)
+void launch_jacobi_pair<double>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const double* src,
+                                const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
+                                int z_first, int z_last, int shape, int second_first, double omega)
 {
     const int alt = shape < 0 ? 0 : (shape >> 3);
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
-    if (nxw == 1) return launch_pair_v<double, 1, 8>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, edges);
-    else if (nxw == 2) return launch_pair_v<double, 2, 4>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, edges);
-    else if (nxw == 3) return launch_pair_v<double, 3, 3>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, edges);
-    else return launch_pair_v<double, 4, 2>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, edges);
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    else launch_pair_v<double, 4, 2>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
 }
 
 // =====================================================================================

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
                                                                       const T* __restrict__ rhs, T* __restrict__ dst,
                                                                       const uint8_t* __restrict__ flags, int b, T a, T inv_c,
                                                                       int z_first, int z_last, int zc_len, int z_stride,
-                                                                      int nbands, int nblk, EdgeArgs ea)
+                                                                      int nbands, int nblk)
 {
     static_assert(NL == 2 || NL == 3, "two or three sweeps per pass");
     constexpr int BY = NYW * RY, TW = NXW * 256 + 8, RW = NXW * 256;
@@ -73,9 +73,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     __shared__ T ring[NL - 1][2][BY][TW];                // [level-1][plane & 1][tile row][x + 3]
     __shared__ T rsave[NL][BY - 2][RW];                  // thread-private: rhs of the last NL planes
 
-    // SLAB: the leading ea.nblocks workgroups compute the slab's boundary regions (EdgeFirst, kernels.h)
-    const bool edge_block = SLAB && (int)blockIdx.x < ea.nblocks;
-    const int v = edge_block ? (int)blockIdx.x : xcd_contiguous((int)blockIdx.x - (SLAB ? ea.nblocks : 0), nblk);
+    const int v = xcd_contiguous(blockIdx.x, nblk);
     const int band = v % nbands, zc = v / nbands;
     // readfirstlane: the wave index is the same in all 64 lanes, but only this tells the compiler so -- rows,
     // row pointers and every row test then live in scalar registers and branch as scalars
@@ -91,9 +89,9 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     const bool full_group = ALIGNED || (x0 + 3 <= W);
     // physical z walls: both on one GPU; on a slab only the first / last rank has one
     const bool lo_wall = SLAB ? (sc.lo_wall != 0) : true, hi_wall = SLAB ? (sc.hi_wall != 0) : true;
-    const int zbeg = edge_block ? (zc ? ea.second : ea.first) : SLAB ? z_first + zc * z_stride : 1 + zc * zc_len;   // level-NL output planes
-    const int zend = edge_block ? zbeg + ea.planes - 1 : min(SLAB ? z_last : D, zbeg + zc_len - 1);
-    if (zbeg > zend) return;                             // block-uniform (never a boundary workgroup)
+    const int zbeg = SLAB ? z_first + zc * z_stride : 1 + zc * zc_len;                  // level-NL output planes
+    const int zend = min(SLAB ? z_last : D, zbeg + zc_len - 1);
+    if (zbeg > zend) return;                             // block-uniform
     // planes of level j: NL-j beyond the output chunk on each side; beyond a physical wall there is no
     // such plane (its ghost is derived below), beyond a slab boundary it is the neighbour's plane,
     // recomputed here from the NL-deep halo
@@ -405,7 +403,6 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         iter(IC<2>{}, zl);
         if (++zl > zl_end) break;
     }
-    if (edge_block) edge_signal(ea);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -420,20 +417,16 @@ static int fused_bands(int H, int BY)
 }
 
 template <class T, int NL, int NXW, int NYW, int RY>
-static int launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
-                          const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt,
-                          int second_first, const EdgeFirst* edges)
+static void launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
+                           const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt,
+                           int second_first)
 {
     constexpr int BY = NYW * RY, THREADS = NXW * NYW * 64;
     const int planes = z_last - z_first + 1;
-    if (planes <= 0) return 0;
+    if (planes <= 0) return;
     const int nbands = fused_bands<NL>(g.H, BY);
     const bool aligned = (g.W == NXW * 256);
-    EdgeArgs ea = {0, 0, -1, 0, nullptr, nullptr, 0u};
-    if (edges && edges->counter && edges->planes > 0 && second_first < 0)
-        ea = EdgeArgs{nbands * (edges->second >= 0 ? 2 : 1), edges->first, edges->second, edges->planes, edges->counter, edges->signal,
-                      edges->done_before + (unsigned)(nbands * (edges->second >= 0 ? 2 : 1))};
-    const bool whole = sc.lo_wall && sc.hi_wall && z_first == 1 && z_last == g.D && second_first < 0 && ea.nblocks == 0;
+    const bool whole = sc.lo_wall && sc.hi_wall && z_first == 1 && z_last == g.D && second_first < 0;
     int zc_len, z_stride, nblk;
     if (second_first >= 0) {
         // two equally long ranges (the slab's two boundary regions) as two chunks of one launch
@@ -473,14 +466,13 @@ static int launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc&
     // else the general one
     if (aligned && whole)
         hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, true, false>), dim3(nblk), dim3(THREADS), 0, st, g, sc, src,
-                           rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk, ea);
+                           rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk);
     else if (aligned)
-        hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, true, true>), dim3(nblk + ea.nblocks), dim3(THREADS), 0, st, g,
-                           sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk, ea);
+        hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, true, true>), dim3(nblk), dim3(THREADS), 0, st, g, sc, src,
+                           rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk);
     else
-        hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, false, true>), dim3(nblk + ea.nblocks), dim3(THREADS), 0, st, g,
-                           sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk, ea);
-    return ea.nblocks;
+        hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, false, true>), dim3(nblk), dim3(THREADS), 0, st, g, sc, src,
+                           rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk);
 }
 
 // Which (T, NL) this file has a kernel for on this grid.  On a z-slab the halo must be NL planes deep.
@@ -513,13 +505,13 @@ int fused_shape_count<double>(const GridDesc& g, int) { return (g.W <= 256) ? 1 
 // plan = workgroup shape + 8 * (which of the launcher's three best z-chunk counts); all plans give the same bits,
 // the host driver times them once per grid.
 template <>
-int launch_jacobi_fused<float>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int levels,
-                               const float* src, const float* rhs, float* dst, const uint8_t* flags, int b, float a,
-                               float inv_c, int z_first, int z_last, int plan, int second_first, const EdgeFirst* edges)
+void launch_jacobi_fused<float>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int levels,
+                                const float* src, const float* rhs, float* dst, const uint8_t* flags, int b, float a,
+                                float inv_c, int z_first, int z_last, int plan, int second_first)
 {
     if (plan < 0) plan = 0;
     const int alt = plan >> 3, shape = plan & 7;
-#define FS_F(NL, NX, NY, RY) return launch_fused_v<float, NL, NX, NY, RY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, edges)
+#define FS_F(NL, NX, NY, RY) launch_fused_v<float, NL, NX, NY, RY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first)
     if (levels == 3) {
         // Two rows per wave throughout (three rows and 8 waves were slower: the instruction stream of a wave
         // is what limits this kernel).  Rows up to 256 cells: bands of 20, 16 or 12 rows (the smaller ones trade
@@ -541,13 +533,13 @@ int launch_jacobi_fused<float>(hipStream_t st, const SweepTune& tune, const Grid
 #undef FS_F
 }
 template <>
-int launch_jacobi_fused<double>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int,
-                                const double* src, const double* rhs, double* dst, const uint8_t* flags, int b, double a,
-                                double inv_c, int z_first, int z_last, int plan, int second_first, const EdgeFirst* edges)
+void launch_jacobi_fused<double>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int,
+                                 const double* src, const double* rhs, double* dst, const uint8_t* flags, int b, double a,
+                                 double inv_c, int z_first, int z_last, int plan, int second_first)
 {
     if (plan < 0) plan = 0;
     const int alt = plan >> 3, shape = plan & 7;
-#define FS_F(NL, NX, NY, RY) return launch_fused_v<double, NL, NX, NY, RY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, edges)
+#define FS_F(NL, NX, NY, RY) launch_fused_v<double, NL, NX, NY, RY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first)
     // fp64: two sweeps per pass; rows up to 256 cells: 20-row bands; up to 512: 10-row bands (10 waves) or 8 (8 waves, 256 VGPRs)
     if (g.W <= 256) FS_F(2, 1, 10, 2);
     else if (shape == 1) FS_F(2, 2, 4, 2);

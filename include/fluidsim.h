@@ -100,7 +100,7 @@ int fs_destroy(fs_sim* s);
  *                 two-sweep kernels (jacobi_pair_kernel / jacobi_fused_kernel<NL=2>) runs those passes;
  *   "advect_kernels" "cell" (default: one thread per cell) | "row" (four cells per lane, clamp tables; slower);
  *   "sweep_ry" "sweep_zc" "sweep_blocks" "pair_zc" "pair_shape" "project_kernels" "fuse_advect"
- *   "overlap" "edge_merge" -- see csrc/kernels.h (SweepTune), csrc/fluidsim.cpp and tools/tune_*.py.
+ *   "overlap" ("0" | "1" default | "2") -- see csrc/kernels.h (SweepTune), csrc/fluidsim.cpp and tools/tune_*.py.
  */
 int fs_set_option(fs_sim* s, const char* key, const char* value);
 

@@ -59,7 +59,7 @@ def main():
     out = {F.FIELD_NAMES[f]: sim.get(f) for f in (F.DENS, F.VX, F.VY, F.VZ, F.OBS, F.PRESSURE)}
     stats = np.array(sim.stats(F.DENS) + sim.stats(F.VX))
     reach = sim._geti("last_advect_reach")
-    kernels = np.array([sim._geti("triple_plan"), sim._geti("two_sweep_fused"), sim._geti("halo_depth"), sim._geti("edge_merge_active")])
+    kernels = np.array([sim._geti("triple_plan"), sim._geti("two_sweep_fused"), sim._geti("halo_depth")])
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), zoff=zoff, stats=stats, reach=reach, kernels=kernels, **out)
     sim.close()
 

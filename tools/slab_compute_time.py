@@ -17,8 +17,8 @@ rank = int(sys.argv[5]) if len(sys.argv) > 5 else P // 2
 acc = int(sys.argv[6]) if len(sys.argv) > 6 else 80
 steps = int(sys.argv[7]) if len(sys.argv) > 7 else 3
 out = {"grid": [W, H, D], "ranks": P, "rank": rank, "acc": acc}
-for overlap, merge in ((2, 0), (1, 1), (1, 0), (0, 0)):
-    sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0, profile=1, overlap=overlap, edge_merge=merge)
+for overlap in (1, 2, 0):
+    sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0, profile=1, overlap=overlap)
     if P > 1:
         sim.comm_init(rank, P, b"FSNULL:".ljust(128, b"\0"))
     sim.addObstacle(W // 3, H // 2, min(D, sim.z_offset + 2))
@@ -31,7 +31,7 @@ for overlap, merge in ((2, 0), (1, 1), (1, 0), (0, 0)):
     sim.sync()
     dt = (time.perf_counter() - t0) / steps
     fam = {k: sim.timing(k) for k in ("sweep", "sweep_pair", "divergence", "gradient", "advect", "comm", "misc")}
-    out["overlap=%d,edge_merge=%d" % (overlap, merge)] = {"ms_per_step": dt * 1e3, "edge_merge_active": sim._geti("edge_merge_active"), "cells_steps_per_sec_if_all_ranks_alike": W * H * D / dt,
+    out["overlap=%d" % overlap] = {"ms_per_step": dt * 1e3, "cells_steps_per_sec_if_all_ranks_alike": W * H * D / dt,
                                    "kernel_ms_per_step": {k: v[0] / steps for k, v in fam.items()},
                                    "launches_per_step": {k: v[1] / steps for k, v in fam.items()}}
     sim.close()
