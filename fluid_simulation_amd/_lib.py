@@ -85,7 +85,12 @@ def lib():
                                 "g.build()'` or `make -C fluid_simulation_amd/csrc` (no CPU fallback exists)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                if os.environ.get("FLUIDSIM_LIB"):       # development: an older build named explicitly (tools/ab_lib.py)
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L

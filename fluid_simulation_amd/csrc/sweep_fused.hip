@@ -51,7 +51,8 @@ struct IC {
 };
 
 // Experiment switch (build with -DFS_EXP_NT=1|2|3): nontemporal loads of the right-hand side (1) and / or nontemporal
-// stores of the result (2).  See DESIGN.md section 4 for what was measured; the shipped library is built with 0.
+// stores of the result (2).  Measured at 512^3 on one box (profiles/r02k_nontemporal_ab_c3.json): 0 -> 0.1465, 1 -> 0.150,
+// 2 -> 0.146, 3 -> 0.148 ms per sweep; the shipped library is built with 0.
 #ifndef FS_EXP_NT
 #define FS_EXP_NT 0
 #endif
@@ -79,7 +80,6 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     // row pointers and every row test then live in scalar registers and branch as scalars
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wx = wave % NXW, wy = wave / NXW;
-    if ((FS_EXP_NT & 4) && wave >= (NXW * NYW) / 2) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
     const int W = g.W, H = g.H, D = g.D;
     const int s = band * (BY - 2 * OV);                  // tile row t <-> grid row s + t
     const int ty0 = wy * RY, y0 = s + ty0;
