@@ -66,9 +66,28 @@ int main(int argc, char** argv)
             CHECK(fs_streamlines_fetch(s, off.data(), pts.data(), norm.data()));
             if (off[(size_t)nl] != np) return 6;
         }
+        {   // the viewer's obstacle mesh: extract, then fetch into caller memory
+            long nv = 0, nt = 0;
+            CHECK(fs_obstacle_surface(s, &nv, &nt));
+            std::vector<float> verts((size_t)nv * 3 + 1);
+            std::vector<int> tris((size_t)nt * 3 + 1);
+            CHECK(fs_obstacle_surface_fetch(s, verts.data(), tris.data()));
+            for (long i = 0; i < 3 * nt; ++i)
+                if (tris[(size_t)i] < 0 || tris[(size_t)i] >= nv) return 7;
+            int edges[24];
+            if (fs_surface_case_table(1, edges) != 1 || fs_surface_case_table(256, edges) != FS_EINVAL) return 8;
+        }
         CHECK(fs_set_option(s, "sweep_fuse", "4"));     // force the three-sweep kernel (fp32 only; fp64 keeps pairs)
         CHECK(fs_run_one(s));
         CHECK(fs_set_option(s, "sweep_fuse", "3"));
+        CHECK(fs_set_option(s, "two_sweep_kernel", "fused"));   // jacobi_fused_kernel<NL=2> (fp64 here; fp32 needs rows > 512 cells)
+        CHECK(fs_run_one(s));
+        CHECK(fs_set_option(s, "two_sweep_kernel", "pair"));
+        CHECK(fs_run_one(s));
+        CHECK(fs_set_option(s, "two_sweep_kernel", "auto"));
+        CHECK(fs_set_option(s, "advect_kernels", "row"));
+        CHECK(fs_run_one(s));
+        CHECK(fs_set_option(s, "advect_kernels", "cell"));
         CHECK(fs_set_option(s, "solver", "gs_lex"));
         CHECK(fs_run_one(s));
         CHECK(fs_destroy(s));
