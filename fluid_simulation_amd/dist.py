@@ -41,25 +41,56 @@ def max_over_ranks(dist, value, device=None):
     return float(t.item())
 
 
-def exchange_halo_planes(dist, field, rank, nranks):
+def halo_depth(fp64, width, local_depth):
+    """Halo planes a slab keeps per side (Engine::init, csrc/fluidsim.cpp): as many as the deepest fused
+    solver pass has levels -- three where the three-sweep kernel exists (fp32, rows up to 512 cells), else two."""
+    return 3 if (not fp64 and width <= 512 and local_depth >= 3) else 2
+
+
+def pass_plan(sweeps, can3, can2, rbsor=False):
+    """The passes of one solve (Engine::solve): levels per pass -- three sweeps while at least three remain
+    (where that kernel exists), then two, then one; an rbsor iteration is one two-level pass.  Every rank
+    derives the same list: it fixes the depth of every halo exchange."""
+    plan, left = [], sweeps
+    while left > 0:
+        if rbsor:
+            plan.append(2)
+            left -= 1
+            continue
+        lv = 3 if (can3 and left >= 3) else 2 if (can2 and left >= 2) else 1
+        plan.append(lv)
+        left -= lv
+    return plan
+
+
+def exchange_depths(plan, zh):
+    """Planes exchanged per direction after each pass: what the NEXT pass needs (its level count); after
+    the last pass the halos are brought to their full depth, which every other kernel assumes."""
+    return [plan[i + 1] if i + 1 < len(plan) else zh for i in range(len(plan))]
+
+
+def exchange_halo_planes(dist, field, rank, nranks, depth=1, zh=1):
     """Reference statement of the halo rule the C++ transports implement (csrc/comm.h
-    exchange_halo), on a (D_local+2, ...) torch tensor: my plane 1 becomes the lower neighbour's
-    plane D+1, my plane D the upper neighbour's plane 0; wall planes are left alone."""
+    exchange_halo), on a (D_local + 2*zh, ...) torch tensor whose index i holds local plane i - zh + 1:
+    my planes 1..depth become the lower neighbour's planes D+1..D+depth, my planes D-depth+1..D the upper
+    neighbour's planes 1-depth..0; wall planes are left alone."""
+    n = field.shape[0] - 2 * zh                      # local depth D
+    at = lambda z: z + zh - 1                        # noqa: E731  local plane -> index
     ops = []
     lo = hi = None
     if rank > 0:
-        ops.append(dist.P2POp(dist.isend, field[1].contiguous(), rank - 1))
-        lo = field[0].clone()
+        ops.append(dist.P2POp(dist.isend, field[at(1):at(depth) + 1].contiguous(), rank - 1))
+        lo = field[at(1 - depth):at(0) + 1].clone()
         ops.append(dist.P2POp(dist.irecv, lo, rank - 1))
     if rank < nranks - 1:
-        ops.append(dist.P2POp(dist.isend, field[-2].contiguous(), rank + 1))
-        hi = field[-1].clone()
+        ops.append(dist.P2POp(dist.isend, field[at(n - depth + 1):at(n) + 1].contiguous(), rank + 1))
+        hi = field[at(n + 1):at(n + depth) + 1].clone()
         ops.append(dist.P2POp(dist.irecv, hi, rank + 1))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     if lo is not None:
-        field[0].copy_(lo)
+        field[at(1 - depth):at(0) + 1].copy_(lo)
     if hi is not None:
-        field[-1].copy_(hi)
+        field[at(n + 1):at(n + depth) + 1].copy_(hi)
     return field
