@@ -50,7 +50,7 @@ def kernels_sha():
     """Identity of the kernel sources a PMC measurement belongs to (profiles/sweep_traffic.json stamps)."""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("kernels.hip", "kernels.h"):
+    for fn in ("kernels.hip", "sweep_fused.hip", "kernels.h", "kernels_dev.h"):
         with open(os.path.join(ROOT, "fluid_simulation_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
