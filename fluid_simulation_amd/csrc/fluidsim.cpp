@@ -204,7 +204,7 @@ struct Engine : EngineBase {
     int triple_alt = -1;                // >= 0: three sweeps per pass beat two on this grid (launch plan id)
     hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
     hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_int = nullptr;
-    static constexpr int NRED = 3 * 1024 + 3;
+    static constexpr int NRED = 3 * 1024 + 12;   // reduction scratch + up to four {sum, min, max} results
 
     explicit Engine(fs_sim* s) : S(s) {}
 
@@ -722,13 +722,23 @@ struct Engine : EngineBase {
     // max |u_z| over them (device reduction + all-reduce), times dt*D, plus the floor()/corner margin.
     int trace_reach(std::initializer_list<int> fields, int* reach)
     {
-        double umax = 0.0;
+        // every field's reduction and all-reduce is queued first; ONE copy and ONE host synchronisation fetch them all
+        // (the window sizes are arguments of host-side send/recv calls, so the host has to know the reach)
+        double st[4][3];
+        int k = 0;
         for (int f : fields) {
-            double st3[3];
-            int rc = stats_of(arr[slot[f]], st3);
-            if (rc) return rc;
-            umax = std::fmax(umax, std::fmax(std::fabs(st3[1]), std::fabs(st3[2])));
+            if (k >= 4) break;
+            double* out3 = red + 3 * 1024 + 3 * k;
+            const int zlo = sc.lo_wall ? 0 : 1, zhi = sc.hi_wall ? g.D + 1 : g.D;
+            fs::launch_stats<T>(S->stream, g, arr[slot[f]], out3, red, 3 * 1024, zlo, zhi);
+            if (S->comm.active() && S->comm.reduce_stats(S->stream, out3, g, S->D))
+                return fail(FS_ECOMM, "stats all-reduce failed: %s", S->comm.last_error());
+            ++k;
         }
+        HIP_TRY(hipMemcpyAsync(&st[0][0], red + 3 * 1024, 3 * k * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        double umax = 0.0;
+        for (int i = 0; i < k; ++i) umax = std::fmax(umax, std::fmax(std::fabs(st[i][1]), std::fabs(st[i][2])));
         const double planes = std::ceil(std::fabs((double)S->dt * (double)S->D) * umax) + 2.0;
         *reach = planes >= (double)S->D ? S->D : (int)planes;
         S->last_reach = *reach;
