@@ -102,3 +102,43 @@ def test_depth_must_divide(tmp_path):
     sim = F.Simulation(8, 8, 9, 1, quiet=1)
     with pytest.raises(F.FluidsimError):
         sim.comm_init(0, 2, F.comm_unique_id("shm"))
+
+
+def _soak_cases():
+    """Seeded random slab configurations: rank counts, slab depths down to the halo depth, row widths around the
+    kernels' limits (256, 512, 1024 cells), both precisions, every overlap mode and two-sweep kernel.  FS_SOAK=N draws N
+    cases instead of the default handful (development soak; every case is a full bit-exact comparison)."""
+    n = int(os.environ.get("FS_SOAK", "6"))
+    rng = np.random.default_rng(20261005)
+    cases = []
+    for i in range(n):
+        nranks = int(rng.choice([2, 2, 3, 4]))
+        dl = int(rng.choice([3, 4, 5, 7, 10, 14, 16, 19]))
+        W = int(rng.choice([rng.integers(11, 48), rng.integers(250, 262), rng.integers(505, 520), rng.integers(1015, 1030)],
+                           p=[0.5, 0.2, 0.2, 0.1]))
+        H = int(rng.integers(7, 26))
+        acc = int(rng.integers(1, 10))
+        prec = str(rng.choice(["fp32", "fp32", "fp64"]))
+        opts = ["overlap=%d" % int(rng.integers(0, 3)), "two_sweep_kernel=%s" % rng.choice(["auto", "pair", "fused"])]
+        if rng.random() < 0.25:
+            opts.append("sweep_fuse=2")
+        cases.append((i, W, H, dl * nranks, nranks, acc, prec, ",".join(opts)))
+    return cases
+
+
+@pytest.mark.parametrize("case,W,H,D,nranks,acc,precision,opts", _soak_cases())
+def test_random_slab_configurations_match_single_gpu(tmp_path, case, W, H, D, nranks, acc, precision, opts):
+    args = [W, H, D, acc, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision, "jacobi", opts]
+    ref_dir = run_ranks(str(tmp_path), 1, args)
+    par_dir = run_ranks(str(tmp_path), nranks, args)
+    ref = np.load(os.path.join(ref_dir, "rank0.npz"))
+    Dl = D // nranks
+    u = np.uint64 if precision == "fp64" else np.uint32
+    for r in range(nranks):
+        z = np.load(os.path.join(par_dir, "rank%d.npz" % r))
+        zoff = int(z["zoff"])
+        for k in ("dens", "v_x", "v_y", "v_z", "obs", "pressure"):
+            got, want = z[k], ref[k][zoff:zoff + Dl + 2]
+            lo = 0 if r == 0 else 1
+            hi = Dl + 2 if r == nranks - 1 else Dl + 1
+            assert np.array_equal(got[lo:hi].view(u), want[lo:hi].view(u)), (case, r, k)
