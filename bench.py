@@ -310,10 +310,11 @@ def main():
     traffic, traffic_note = None, "no PMC measurement committed for this workload/kernel"
     triple_plan = sim._geti("triple_plan")
     tpath = os.path.join(ROOT, "profiles", "sweep_traffic.json")
-    if os.path.exists(tpath) and args.precision == "fp32":
+    tkey = name + ("_fp64" if args.precision == "fp64" else "")
+    if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                entry = json.load(f).get(name, {}).get(kernel, {})
+                entry = json.load(f).get(tkey, {}).get(kernel, {})
             stamp = entry.get("stamp") or {}
             want = {"kernels_sha": kernels_sha(), "grid": [W, H, D], "pair_shape": pair_shape, "triple_plan": triple_plan}
             if entry and all(stamp.get(k) == v for k, v in want.items()):

@@ -3,7 +3,8 @@
 #   gpurun --timeout 1200 -- 'tools/make_profiles.sh r02a'
 # and then, back in the container, copy what it left in gpurun_out/profiles_<tag>/ into profiles/ and run
 #   python3 tools/pmc_to_traffic.py gpurun_out/profiles_<tag>/pmc_fetch gpurun_out/profiles_<tag>/pmc_write c3 gpurun_out/profiles_<tag>/pmc_fetch_bench.json
-# (rewrites profiles/sweep_traffic.json, which bench.py reads for roofline.traffic).
+# (rewrites profiles/sweep_traffic.json, which bench.py reads for roofline.traffic); likewise pmc_fetch_c4 / pmc_write_c4 with
+# workload c4 and pmc_fetch_c5 / pmc_write_c5 with workload c3_fp64.
 #
 # Rules of the pool this script respects: the profiled program follows `--` directly (python3, no env /
 # bash -c hops); --pmc runs are separate from --kernel-trace/--stats runs; FETCH_SIZE and WRITE_SIZE
@@ -30,4 +31,9 @@ python3 tools/pmc_summary.py $OUT/pmc_sq $OUT/pmc_sq_summary.json > /dev/null
 timeout -k 10 300 $B --workload c2 --steps 10 > $OUT/bench_c2.json 2> /dev/null
 timeout -k 10 300 $B --workload c4 --steps 5 > $OUT/bench_c4_n1.json 2> /dev/null
 timeout -k 10 400 $B --precision fp64 --steps 3 --warmup 1 > $OUT/bench_c5_fp64.json 2> /dev/null
+# 6. HBM traffic of the dominant kernel of configs 4 and 5 (the two-sweep kernel): the same two PMC passes each
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_c4 --output-format csv -- $B --workload c4 --steps 1 --warmup 1 > $OUT/pmc_fetch_c4_bench.json 2> /dev/null
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_c4 --output-format csv -- $B --workload c4 --steps 1 --warmup 1 > /dev/null 2> /dev/null
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_c5 --output-format csv -- $B --precision fp64 --steps 1 --warmup 1 > $OUT/pmc_fetch_c5_bench.json 2> /dev/null
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_c5 --output-format csv -- $B --precision fp64 --steps 1 --warmup 1 > /dev/null 2> /dev/null
 ls -la $OUT

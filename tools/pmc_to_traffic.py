@@ -22,7 +22,7 @@ import subprocess  # noqa: E402
 
 from bench import WORKLOADS, kernels_sha  # noqa: E402
 
-stamp = {"kernels_sha": kernels_sha(), "grid": [WORKLOADS[workload][k] for k in ("W", "H", "D")]}
+stamp = {"kernels_sha": kernels_sha(), "grid": [WORKLOADS[workload.split("_")[0]][k] for k in ("W", "H", "D")]}   # "c3_fp64" -> c3's grid
 try:
     stamp["commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:  # noqa: BLE001
