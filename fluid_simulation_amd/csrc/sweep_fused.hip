@@ -27,11 +27,14 @@
 // Bands overlap by 2(NL-1) rows and z chunks by 2(NL-1) planes.
 //
 // Instantiations (LDS = (NL-1)*2*BY*TW + NL*(BY-2)*RW elements must stay under 160 KB):
-//   fp32 NL=3  rows <= 512 cells   the solver kernel at 256^3 and 512^3: 0.42 ms per pass at 512^3
-//                                  = 0.14 ms per sweep, 12 waves of two rows, 150 VGPRs, no scratch
+//   fp32 NL=3  rows <= 512 cells   the solver kernel at 256^3 and 512^3: 0.43 ms per pass at 512^3
+//                                  = 0.14 ms per sweep, 12 waves of two rows, 152 VGPRs, no scratch
 //   fp32 NL=2  rows 513..1024      config 4: bands of 8 or 9 rows (6 or 7 productive) where the older
 //                                  jacobi_pair_kernel (kernels.hip) only fits 6 (4 productive)
 //   fp64 NL=2  rows <= 512         config 5: bands of 10 rows (8 productive) against 8 (6)
+// The two NL=2 families are candidates of the host's one-off timing, which so far always prefers the pair
+// kernel to them (0.83 vs 0.71 ms at 1024x512x512, 0.84 vs 0.77 fp64 at 512^3: both sit at the same memory
+// ceiling, and per level this structure costs more instructions); three sweeps per pass is where it pays.
 // SLAB = true adds what a z-slab of a multi-GPU run needs: an output plane range (the boundary
 // regions are computed first), no physical wall on a side that borders another slab -- the levels
 // are then computed NL-1 planes into the neighbour's planes from the NL-deep halo -- and an optional
