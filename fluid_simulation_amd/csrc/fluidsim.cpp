@@ -1366,6 +1366,11 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         if (v == "cell") s->tune.advect_cell = 1;
         else if (v == "row") s->tune.advect_cell = 0;
         else return fail(FS_EINVAL, "advect_kernels: row | cell");
+    } else if (k == "wall_free") {
+        if (v == "0") s->tune.wall_free = 0;
+        else if (v == "auto") s->tune.wall_free = 1;
+        else if (v == "1") s->tune.wall_free = 2;
+        else return fail(FS_EINVAL, "wall_free: 0 | auto | 1");
     } else if (k == "pair_zc") {
         s->tune.pair_zc = atoi(value);
     } else if (k == "pair_shape") {

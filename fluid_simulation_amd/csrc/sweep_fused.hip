@@ -62,7 +62,7 @@ struct IC {
 template <class T>
 using Vec4 = T __attribute__((ext_vector_type(4)));
 
-template <class T, int NL, int NXW, int NYW, int RY, bool ALIGNED, bool SLAB>
+template <class T, int NL, int NXW, int NYW, int RY, bool ALIGNED, bool SLAB, int WALLSEL>
 __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                                       const T* __restrict__ rhs, T* __restrict__ dst,
                                                                       const uint8_t* __restrict__ flags, int b, T a, T inv_c,
@@ -102,10 +102,17 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     const int lo1 = max(zlo_lim, zbeg - OV), hi1 = min(zhi_lim, zend + OV);             // level-1 planes
     const int lo2 = max(zlo_lim, zbeg - (OV - 1)), hi2 = min(zhi_lim, zend + (OV - 1)); // level-2 planes
     const int zmax0 = hi_wall ? D + 1 : D + NL, zmax1 = hi_wall ? D : D + OV;           // last level-0 / level-1 plane that exists
+    // Everything below can exist twice (WALLSEL = 1): the general body, and one for workgroups that touch no wall in y or z
+    // (interior bands x interior z chunks), in which every wall test, ghost row / ghost plane and the registers that carry
+    // them are compiled out -- 523 instead of 837 instructions per plane, 126 instead of 152 VGPRs on its own.  The two are
+    // separate loops selected once per workgroup (two bodies inside ONE loop spill at their merge, round 1).
+    auto run = [&](auto wallc) {
+    constexpr bool WALLS = decltype(wallc)::value != 0;
+    const bool lo_wall_c = WALLS && lo_wall, hi_wall_c = WALLS && hi_wall;      // the ghost-plane code of the physical z walls
     // rows a level can be computed for: one fewer per level at a band edge, none lost at a wall
-    const bool top_in_tile = (s + BY - 1 >= H + 1);
-    const int r2lo = (s == 0) ? 1 : s + 1, r2hi = top_in_tile ? H : s + BY - 2;
-    const int r3lo = (s == 0) ? 1 : s + 2, r3hi = top_in_tile ? H : s + BY - 3;
+    const bool top_in_tile = WALLS && (s + BY - 1 >= H + 1), bottom_in_tile = WALLS && (s == 0);
+    const int r2lo = bottom_in_tile ? 1 : s + 1, r2hi = top_in_tile ? H : s + BY - 2;
+    const int r3lo = bottom_in_tile ? 1 : s + 2, r3hi = top_in_tile ? H : s + BY - 3;
     const int kill_shift = (b == 0) ? 0 : 4;
     const T zero = (T)0;
 
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         lds_set(&tl[t][x0 + 3], st);
         if (x0 == 1) tl[t][3] = (b == 1) ? -u[0] : u[0];                                          // :189-190
         if (full_group && x0 + 3 == W) tl[t][W + 4] = u[3];                                       // :191
-        if (y == 1 || y == H) {
+        if (WALLS && (y == 1 || y == H)) {
             T f[4];
             face4(u, b == 2, f);
             if (y == 1 && t >= 1) lds_set(&tl[t - 1][x0 + 3], f);                                  // :198-199
@@ -232,11 +239,11 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         const T left = tl[t][x0 + 2];                    // neighbour lane's / wave's cell, or the ghost column x = 0
         const T right = tl[t][x0 + 7];                   // ... or the ghost column x = W+1
         T ym[4], yp[4];
-        if (r > 0 && y != 1) {
+        if (r > 0 && (!WALLS || y != 1)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) ym[e] = s1[r > 0 ? r - 1 : 0][e];
         } else lds_get(&tl[t - 1][x0 + 3], ym);          // another wave's row, or the ghost row y = 0
-        if (r < RY - 1 && y != H) {
+        if (r < RY - 1 && (!WALLS || y != H)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) yp[e] = s1[r < RY - 1 ? r + 1 : r][e];
         } else lds_get(&tl[t + 1][x0 + 3], yp);          // another wave's row, or the ghost row y = H+1
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         }
         if (x0 == 1) *reinterpret_cast<T*>(base - ES) = (b == 1) ? -u[0] : u[0];                    // :189-190
         if (full_group && x0 + 3 == W) *reinterpret_cast<T*>(base + 4 * ES) = u[3];                // :191
-        if (y == 1 || y == H) {
+        if (WALLS && (y == 1 || y == H)) {
             T f[4];
             V4<T> qq;
             face4(u, b == 2, f);
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
             if (y == 1) *reinterpret_cast<V4<T>*>(base - row_b) = qq;                               // :198-201
             if (y == H) *reinterpret_cast<V4<T>*>(base + row_b) = qq;
         }
-        const bool zlo_face = (zo == 1) && lo_wall, zhi_face = (zo == D) && hi_wall;
+        const bool zlo_face = (zo == 1) && lo_wall_c, zhi_face = (zo == D) && hi_wall_c;
         if (zlo_face || zhi_face) {
             T f[4];
             V4<T> qq;
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         // the rhs ring: NL = 3 rotates with the register slots (compile-time slot), NL = 2 by plane parity
         T(*rs_put)[RW] = rsave[(NL == 3) ? PH : (zl & 1)];
         T(*rs_get2)[RW] = rsave[(NL == 3) ? I2 : ((zl - 1) & 1)];
-        const bool wall_lo1 = (zl == 1) && lo_wall, wall_hi1 = (zl == D) && hi_wall;
+        const bool wall_lo1 = (zl == 1) && lo_wall_c, wall_hi1 = (zl == D) && hi_wall_c;
         if (zl <= hi1) {                                 // ---- level 1 of plane zl
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         asm volatile("" ::: "memory");                   // (the IR-level sink pass does the same across blocks)
         __builtin_amdgcn_sched_barrier(0);
         const int P2 = zl - 1;
-        const bool wall_lo2 = (P2 == 1) && lo_wall, wall_hi2 = (P2 == D) && hi_wall;
+        const bool wall_lo2 = (P2 == 1) && lo_wall_c, wall_hi2 = (P2 == D) && hi_wall_c;
         if constexpr (NL == 3) {
             if (P2 >= lo2 && P2 <= hi2) {                // ---- level 2 of plane zl-1 (intermediate)
 #pragma unroll
@@ -406,6 +413,11 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         iter(IC<2>{}, zl);
         if (++zl > zl_end) break;
     }
+    };
+    // a workgroup needs the general body if one of its rows is a wall row or one of its level planes a wall plane
+    const bool interior = (s > 0) && (s + BY - 1 < H) && (!lo_wall || lo1 >= 2) && (!hi_wall || hi1 <= D - 1);
+    if (WALLSEL == 1 && interior) run(IC<0>{});
+    else run(IC<1>{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,15 +479,19 @@ static void launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc
     }
     // whole-domain, lane-aligned rows (the benchmark grids) get the build without any slab logic; everything
     // else the general one
-    if (aligned && whole)
-        hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, true, false>), dim3(nblk), dim3(THREADS), 0, st, g, sc, src,
-                           rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk);
-    else if (aligned)
-        hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, true, true>), dim3(nblk), dim3(THREADS), 0, st, g, sc, src,
-                           rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk);
-    else
-        hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, false, true>), dim3(nblk), dim3(THREADS), 0, st, g, sc, src,
-                           rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk);
+#define FS_LAUNCH(AL, SL, WS)                                                                                            \
+    hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, AL, SL, WS>), dim3(nblk), dim3(THREADS), 0, st, g, sc, src, \
+                       rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk)
+    // The wall-free second body exists for the three-sweep kernel on lane-aligned whole-domain grids (the benchmark grids).
+    // It is 9 % (512^3) to 14 % (256^3) faster per workgroup, but a pass ends with its slowest workgroup: it only pays when a
+    // CU works through several workgroups (256^3: -2.5 %); with one workgroup per CU (512^3: 256 workgroups) the general
+    // ones set the time and the larger kernel costs 1 % (profiles/r03c_*, r03d_*).  "auto" therefore asks for > 256 workgroups.
+    const bool two_bodies = tune.wall_free == 2 || (tune.wall_free == 1 && nblk > 256);
+    if (aligned && whole && NL == 3 && two_bodies) FS_LAUNCH(true, false, 1);
+    else if (aligned && whole) FS_LAUNCH(true, false, 0);
+    else if (aligned) FS_LAUNCH(true, true, 0);
+    else FS_LAUNCH(false, true, 0);
+#undef FS_LAUNCH
 }
 
 // Which (T, NL) this file has a kernel for on this grid.  On a z-slab the halo must be NL planes deep.

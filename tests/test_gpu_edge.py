@@ -194,6 +194,30 @@ def test_three_sweeps_per_pass_kernel_full_rows(F):
             assert bits_equal(out[0][f], out[1][f]), "%dx%dx%d %s" % (W, H, D, F.FIELD_NAMES[f])
 
 
+@pytest.mark.parametrize("shape,zc", [((512, 45, 40), 8), ((256, 70, 33), 5), ((256, 25, 24), 0), ((512, 10, 9), 3)])
+def test_three_sweeps_wall_free_body_is_bit_identical(F, shape, zc):
+    """wall_free=1: workgroups of the three-sweep kernel whose band and z chunk touch no wall run the second,
+    wall-free body.  Forced here on grids with interior bands and (pair_zc) interior z chunks, with solids in the
+    corners and in the middle, against the single general body; also a grid with no interior workgroup at all."""
+    W, H, D = shape
+    out = []
+    for wf in ("1", "0"):
+        sim = F.Simulation(W, H, D, 1, acc=10, quiet=1, wall_free=wf)
+        sim.set_option("sweep_fuse", "4")
+        if zc:
+            sim.set_option("pair_zc", zc)
+        m = ball_mask(W, H, D, W / 3.0, H / 2.0, D / 2.0, min(H, D) / 3.0)
+        m[1, 1, 1] = m[D, H, W] = True
+        sim.set_mask(m)
+        sim.run_one()
+        sim.run_one()
+        out.append([sim.get(f) for f in range(11)])
+        sim.set_option("sweep_fuse", "3")
+        sim.close()
+    for f in range(11):
+        assert bits_equal(out[0][f], out[1][f]), "%dx%dx%d %s" % (W, H, D, F.FIELD_NAMES[f])
+
+
 @pytest.mark.parametrize("shape,acc,omega,fp64", [((14, 9, 7), 5, 1.0, False), ((33, 21, 5), 4, 1.7, False),
                                                   ((300, 13, 9), 3, 1.5, False), ((1, 1, 1), 2, 1.9, False),
                                                   ((20, 12, 10), 4, 1.6, True)])
