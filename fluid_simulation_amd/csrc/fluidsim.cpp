@@ -1364,8 +1364,9 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         else return fail(FS_EINVAL, "project_kernels: march | cell");
     } else if (k == "advect_kernels") {
         if (v == "cell") s->tune.advect_cell = 1;
+        else if (v == "celltab") s->tune.advect_cell = 2;
         else if (v == "row") s->tune.advect_cell = 0;
-        else return fail(FS_EINVAL, "advect_kernels: row | cell");
+        else return fail(FS_EINVAL, "advect_kernels: cell | celltab | row");
     } else if (k == "wall_free") {
         if (v == "0") s->tune.wall_free = 0;
         else if (v == "auto") s->tune.wall_free = 1;

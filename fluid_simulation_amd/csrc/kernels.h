@@ -50,8 +50,8 @@ struct SweepTune {
     int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic
     int project_cell = 0;     // 1 = per-cell divergence/gradient kernels instead of the z-marching ones
     int pair_shape = 0;       // >0 forces a pair-kernel workgroup shape (1 = 8, 2 = 10, 3 = 16 waves); 0 = timed choice
-    int advect_cell = 1;      // 1 (default) = per-cell advection kernels; 0 = the row kernels (four cells per lane + clamp tables),
-                              // bit-identical but measured slower (profiles/r02g_advect_row_vs_cell_*.json)
+    int advect_cell = 1;      // 1 (default) = per-cell advection kernels; 2 = the same with clamp tables; 0 = the row kernels (four
+                              // cells per lane + clamp tables); bit-identical, within 5 % of each other (profiles/r03e_*, r02g_*)
     int wall_free = 1;        // three-sweep kernel, whole-domain aligned grids: workgroups that touch no y / z wall run a wall-free
                               // second body -- 0 never, 1 (default) when a launch has more than 256 workgroups, 2 always
     int two_kind = 0;         // which two-sweep kernel: 0 = timed choice, 1 = jacobi_pair_kernel only, 2 = jacobi_fused_kernel<NL=2> only

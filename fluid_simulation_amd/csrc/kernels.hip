@@ -1182,10 +1182,16 @@ template <class T>
 __device__ __forceinline__ T clamp_ref(T v, T lo, T hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }   // std::clamp
 
 template <class T>
+__device__ __forceinline__ T back_trace_tab(const GridDesc& g, const SlabCtx& sc, const T* __restrict__ src, long zshift,
+                                            const T* __restrict__ tab, int x, int y, int z, T ux, T uy, T uz, T kx, T ky, T kz);
+
+// TAB: traces whose x coordinate clamps read the pre-interpolated inlet / outlet column tables (see
+// advect_columns_kernel below) instead of the eight scattered values of the big array.
+template <class T, bool TAB>
 __global__ __launch_bounds__(256) void advect_kernel(GridDesc g, SlabCtx sc, int b, T* __restrict__ field,
                                                       const T* __restrict__ prev, const T* vx, const T* vy,
                                                       const T* vz, const uint8_t* __restrict__ flags, T kx, T ky, T kz,
-                                                      long prev_zshift)
+                                                      long prev_zshift, const T* __restrict__ tab)
 {
     const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int y = 1 + blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);   // cell_block(): a wave is one row
@@ -1200,6 +1206,9 @@ __global__ __launch_bounds__(256) void advect_kernel(GridDesc g, SlabCtx sc, int
         const T ux = (b == 1) ? own : vx[c];             // :380-382
         const T uy = (b == 2) ? own : vy[c];
         const T uz = (b == 3) ? own : vz[c];
+        if constexpr (TAB) {
+            u = back_trace_tab<T>(g, sc, prev, prev_zshift, tab, x, y, z, ux, uy, uz, kx, ky, kz);
+        } else {
         const int zg = z + sc.zoff;                      // global plane index
         T px = clamp_ref<T>((T)x - kx * ux, half, (T)g.W + half);          // :384-390
         T py = clamp_ref<T>((T)y - ky * uy, half, (T)g.H + half);
@@ -1214,6 +1223,7 @@ __global__ __launch_bounds__(256) void advect_kernel(GridDesc g, SlabCtx sc, int
         const T b0 = a00 * (one - ty) + a10 * ty;                             // :417-418
         const T b1 = a01 * (one - ty) + a11 * ty;
         u = b0 * (one - tz) + b1 * tz;                                        // :420
+        }
     }
     const bool kill = (b != 0) && (f & F_NEAR);
     field[c] = kill ? (T)0 : u;
@@ -1246,13 +1256,13 @@ __device__ __forceinline__ T back_trace(const GridDesc& g, const SlabCtx& sc, co
     return b0 * (one - tz) + b1 * tz;                                     // :420
 }
 
-template <class T>
+template <class T, bool TAB>
 __global__ __launch_bounds__(256) void advect_velocity_kernel(GridDesc g, SlabCtx sc, T* __restrict__ vx,
                                                                T* __restrict__ vy, T* __restrict__ vz,
                                                                const T* __restrict__ px, const T* __restrict__ py,
                                                                const T* __restrict__ pz,
                                                                const uint8_t* __restrict__ flags, T kx, T ky, T kz,
-                                                               long zshift)
+                                                               long zshift, const T* __restrict__ tab)
 {
     const int x = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int y = 1 + blockIdx.y * blockDim.y + __builtin_amdgcn_readfirstlane(threadIdx.y);   // cell_block(): a wave is one row
@@ -1265,11 +1275,20 @@ __global__ __launch_bounds__(256) void advect_velocity_kernel(GridDesc g, SlabCt
     T sx = (T)0, sy = (T)0;                              // what setBounds leaves in v_x, v_y
     if (!(f & F_SOLID)) {
         const T oy = vy[c], oz = vz[c];
-        nx = back_trace<T>(g, sc, px, zshift, x, y, z, px[c + zshift], oy, oz, kx, ky, kz);
-        sx = near ? (T)0 : nx;
-        ny = back_trace<T>(g, sc, py, zshift, x, y, z, sx, py[c + zshift], oz, kx, ky, kz);
-        sy = near ? (T)0 : ny;
-        nz = back_trace<T>(g, sc, pz, zshift, x, y, z, sx, sy, pz[c + zshift], kx, ky, kz);
+        if constexpr (TAB) {
+            const long plane2 = 2 * (long)(g.H + 2) * (g.D + 2);
+            nx = back_trace_tab<T>(g, sc, px, zshift, tab, x, y, z, px[c + zshift], oy, oz, kx, ky, kz);
+            sx = near ? (T)0 : nx;
+            ny = back_trace_tab<T>(g, sc, py, zshift, tab + plane2, x, y, z, sx, py[c + zshift], oz, kx, ky, kz);
+            sy = near ? (T)0 : ny;
+            nz = back_trace_tab<T>(g, sc, pz, zshift, tab + 2 * plane2, x, y, z, sx, sy, pz[c + zshift], kx, ky, kz);
+        } else {
+            nx = back_trace<T>(g, sc, px, zshift, x, y, z, px[c + zshift], oy, oz, kx, ky, kz);
+            sx = near ? (T)0 : nx;
+            ny = back_trace<T>(g, sc, py, zshift, x, y, z, sx, py[c + zshift], oz, kx, ky, kz);
+            sy = near ? (T)0 : ny;
+            nz = back_trace<T>(g, sc, pz, zshift, x, y, z, sx, sy, pz[c + zshift], kx, ky, kz);
+        }
     }
     vx[c] = near ? (T)0 : nx;
     vy[c] = near ? (T)0 : ny;
@@ -1440,12 +1459,16 @@ void launch_advect_velocity(hipStream_t st, const SweepTune& tune, const GridDes
                             const T* px, const T* py, const T* pz, const uint8_t* flags, const uint8_t* kill, T* coltab, T kx,
                             T ky, T kz, long zshift)
 {
+    const T* tab = (tune.advect_cell == 1) ? nullptr : build_columns<T>(st, g, sc, px, py, pz, 3, coltab, zshift);
     if (tune.advect_cell) {
-        hipLaunchKernelGGL((advect_velocity_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, px, py, pz, flags,
-                           kx, ky, kz, zshift);
+        if (tab)
+            hipLaunchKernelGGL((advect_velocity_kernel<T, true>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, px, py,
+                               pz, flags, kx, ky, kz, zshift, tab);
+        else
+            hipLaunchKernelGGL((advect_velocity_kernel<T, false>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, px, py,
+                               pz, flags, kx, ky, kz, zshift, tab);
         return;
     }
-    const T* tab = build_columns<T>(st, g, sc, px, py, pz, 3, coltab, zshift);
     hipLaunchKernelGGL((advect_velocity_row_kernel<T>), row_grid(g), dim3(256), 0, st, g, sc, vx, vy, vz, px, py, pz, kill, tab,
                        kx, ky, kz, zshift);
 }
@@ -1461,12 +1484,16 @@ void launch_advect(hipStream_t st, const SweepTune& tune, const GridDesc& g, con
                    const T* vx, const T* vy, const T* vz, const uint8_t* flags, const uint8_t* kill, T* coltab, T kx, T ky, T kz,
                    long prev_zshift)
 {
+    const T* tab = (tune.advect_cell == 1) ? nullptr : build_columns<T>(st, g, sc, prev, prev, prev, 1, coltab, prev_zshift);
     if (tune.advect_cell) {
-        hipLaunchKernelGGL((advect_kernel<T>), cell_grid(g), cell_block(), 0, st, g, sc, b, field, prev, vx, vy, vz, flags,
-                           kx, ky, kz, prev_zshift);
+        if (tab)
+            hipLaunchKernelGGL((advect_kernel<T, true>), cell_grid(g), cell_block(), 0, st, g, sc, b, field, prev, vx, vy, vz,
+                               flags, kx, ky, kz, prev_zshift, tab);
+        else
+            hipLaunchKernelGGL((advect_kernel<T, false>), cell_grid(g), cell_block(), 0, st, g, sc, b, field, prev, vx, vy, vz,
+                               flags, kx, ky, kz, prev_zshift, tab);
         return;
     }
-    const T* tab = build_columns<T>(st, g, sc, prev, prev, prev, 1, coltab, prev_zshift);
     hipLaunchKernelGGL((advect_row_kernel<T>), row_grid(g), dim3(256), 0, st, g, sc, b, field, prev, vx, vy, vz, kill, tab, kx,
                        ky, kz, prev_zshift);
 }

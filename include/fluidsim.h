@@ -98,7 +98,8 @@ int fs_destroy(fs_sim* s);
  *                 ranks keep one exchange schedule), "4" three wherever that kernel exists;
  *   "two_sweep_kernel" "auto" (default: timed once per grid) | "pair" | "fused" -- which of the two
  *                 two-sweep kernels (jacobi_pair_kernel / jacobi_fused_kernel<NL=2>) runs those passes;
- *   "advect_kernels" "cell" (default: one thread per cell) | "row" (four cells per lane, clamp tables; slower);
+ *   "advect_kernels" "cell" (default: one thread per cell) | "celltab" (the same reading clamped traces from the
+ *                 column tables) | "row" (four cells per lane, clamp tables); all bit-identical, none faster by > 5 %;
  *   "wall_free"   "auto" (default) | "0" | "1": whether workgroups of the three-sweep kernel that touch no wall run its
  *                 wall-free second body (auto: when a launch has more than 256 workgroups);
  *   "sweep_ry" "sweep_zc" "sweep_blocks" "pair_zc" "pair_shape" "project_kernels" "fuse_advect"
