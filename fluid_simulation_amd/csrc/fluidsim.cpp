@@ -14,6 +14,7 @@
 #include "dump.h"
 #include "streamlines.h"
 #include "surface.h"
+#include "multigrid.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -47,8 +48,8 @@ int fail(int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail(FS_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-enum Family { FAM_SWEEP = 0, FAM_PAIR, FAM_TRIPLE, FAM_DIV, FAM_GRAD, FAM_ADVECT, FAM_BOUNDS, FAM_MISC, FAM_COMM, FAM_COUNT };
-const char* const kFamilyNames[FAM_COUNT] = { "sweep", "sweep_pair", "sweep_triple", "divergence", "gradient", "advect", "bounds", "misc", "comm" };
+enum Family { FAM_SWEEP = 0, FAM_PAIR, FAM_TRIPLE, FAM_DIV, FAM_GRAD, FAM_ADVECT, FAM_BOUNDS, FAM_MISC, FAM_COMM, FAM_MG, FAM_COUNT };
+const char* const kFamilyNames[FAM_COUNT] = { "sweep", "sweep_pair", "sweep_triple", "divergence", "gradient", "advect", "bounds", "misc", "comm", "multigrid" };
 
 constexpr int NPOOL = FS_NFIELDS + 3;   // named fields + ping-pong scratch
 
@@ -84,6 +85,7 @@ struct EngineBase {
     virtual int streamlines(int density, double proximity, int max_length, double step_size, double threshold) = 0;
     virtual int obstacle_surface() = 0;
     virtual int reference_order_sum(int which, double* out) = 0;
+    virtual int multigrid_levels() const = 0;
 };
 
 struct fs_sim {
@@ -94,6 +96,7 @@ struct fs_sim {
     bool fp64 = false;
     int solver = FS_SOLVER_JACOBI;
     float omega = 1.0f;          // relaxation factor of solver=rbsor
+    int mg_cycles = 8, mg_pre = 1, mg_post = 1, mg_coarse = 30;   // solver=mg: V-cycles per pressure solve, smoothing steps, coarsest-level iterations
     std::string dump_dir = "data";
     int dump_every = 1;
     unsigned voxel_seed = 1;
@@ -197,6 +200,9 @@ struct Engine : EngineBase {
     T* gathered = nullptr;              // gathered advection source (z-slabs only), LEAD-shifted global array
     T* gathered3[3] = {nullptr, nullptr, nullptr};   // the same for the three sources of the fused velocity advection
     double* red = nullptr;              // stats scratch
+    T rb_omega = (T)1;                  // relaxation factor of the red-black passes of the running solve
+    fs::Multigrid<T> mg;                // coarse levels of solver=mg; rebuilt when the flag bytes change
+    bool mg_current = false;
     T* coltab = nullptr;                // clamp tables of the advection row kernels: 6 x (H+2)(D+2) (single GPU only)
     static constexpr int FUSED2 = 64;   // pair_shape >= FUSED2: the two-sweep passes run jacobi_fused_kernel<NL = 2>, plan id - FUSED2
     int pair_shape = -1;                // fastest two-sweep launch plan for this grid (timed once)
@@ -278,6 +284,7 @@ struct Engine : EngineBase {
         if (dense) hipFree(dense);
         if (red) hipFree(red);
         if (coltab) hipFree(coltab);
+        mg.release();
         if (ev_edges) hipEventDestroy(ev_edges);
         if (ev_halo) hipEventDestroy(ev_halo);
         if (ev_int) hipEventDestroy(ev_int);
@@ -348,6 +355,7 @@ struct Engine : EngineBase {
         fs::launch_build_flags<T>(S->stream, g, sc, arr[slot[FS_OBS]], flags);
         fs::launch_build_kill(S->stream, g, sc, flags, kill);
         flags_dirty = false;
+        mg_current = false;
         return FS_OK;
     }
 
@@ -366,7 +374,7 @@ struct Engine : EngineBase {
     void launch_pass(hipStream_t st, int levels, bool rb, const T* src_, const T* rhs_, T* dst_, int b, T a, T inv_c, int zf,
                      int zl, int second = -1)
     {
-        const T omega = rb ? (T)S->omega : (T)0;
+        const T omega = rb ? rb_omega : (T)0;
         if (levels == 3)
             fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 3, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, triple_alt, second);
         else if (levels == 2 && !rb && pair_shape >= FUSED2)
@@ -392,7 +400,8 @@ struct Engine : EngineBase {
 
     // Returns the id of the array holding the result (held); `cur` holds the initial
     // iterate (may equal rhs when the caller aliased a snapshot).
-    int solve(int b, int cur, int rhs, T a, T c, int sweeps, int* result)
+    // smoother = true: the red-black form of the update with relaxation factor 1 (level-0 smoother of solver=mg)
+    int solve(int b, int cur, int rhs, T a, T c, int sweeps, int* result, bool smoother = false)
     {
         const T inv_c = (T)1 / c;                        // cRecip, :257
         if (S->solver == FS_SOLVER_GS_LEX) {
@@ -407,9 +416,10 @@ struct Engine : EngineBase {
         int src = cur;
         bool src_temp = false;
         // solver=rbsor: every iteration is one pass of the pair kernel (its two levels are the two colours)
-        const bool rb = (S->solver == FS_SOLVER_RBSOR);
+        const bool rb = smoother || (S->solver == FS_SOLVER_RBSOR);
+        rb_omega = smoother ? (T)1 : (T)S->omega;
         if (rb && !fs::pair_supported<T>(S->tune, g, sc))
-            return fail(FS_EINVAL, "solver=rbsor needs rows of at most 1024 cells and sweep_fuse >= 2");
+            return fail(FS_EINVAL, "solver=rbsor / mg needs rows of at most 1024 cells and sweep_fuse >= 2");
         {
             int rc = ensure_tuned(cur, rhs, b, a, inv_c);
             if (rc) return rc;
@@ -649,6 +659,50 @@ struct Engine : EngineBase {
         return halo(arr[slot[field]]);
     }
 
+    // solver=mg (NOT the reference's arithmetic; defined in oracle/cpu_ref_mg.h): mg_cycles V-cycles on the pressure
+    // equation of :320.  Level 0 is smoothed by red-black passes of the reference's update (the pair kernel), the coarse
+    // levels live in multigrid.hip.  Single GPU.
+    int multigrid_levels() const override { return mg.levels(); }
+    int multigrid_pressure_solve(int* result)
+    {
+        if (S->comm.active()) return fail(FS_EINVAL, "solver=mg is single-GPU (z-slab runs use jacobi or rbsor)");
+        if (S->mg_cycles > 0 && !fs::pair_supported<T>(S->tune, g, sc))
+            return fail(FS_EINVAL, "solver=mg needs rows of at most 1024 cells and sweep_fuse >= 2");
+        if (!mg_current) {
+            ScopedSpan sp(S, FAM_MG);
+            hipError_t e = mg.build(S->stream, g, flags);
+            if (e != hipSuccess) return fail(FS_EHIP, "multigrid levels: %s", hipGetErrorString(e));
+            mg_current = true;
+        }
+        const int own = slot[FS_PRESSURE], rhs = slot[FS_DIVERGENCE];
+        int cur = own;
+        auto smooth = [&](int n) -> int {
+            if (n <= 0) return FS_OK;
+            int res;
+            int rc = solve(0, cur, rhs, (T)1, (T)6, n, &res, true);
+            if (rc) return rc;
+            if (cur != own && cur != res) held[cur] = false;
+            cur = res;
+            return FS_OK;
+        };
+        for (int cyc = 0; cyc < S->mg_cycles; ++cyc) {
+            int rc;
+            if (mg.levels() < 2) {                           // a grid that cannot be halved: the "coarsest level" is level 0
+                if ((rc = smooth(S->mg_coarse))) return rc;
+                continue;
+            }
+            if ((rc = smooth(S->mg_pre))) return rc;
+            {
+                ScopedSpan sp(S, FAM_MG);
+                mg.coarse_correction(S->stream, g, sc, flags, arr[cur], arr[rhs], S->mg_pre, S->mg_post, S->mg_coarse);
+            }
+            if ((rc = smooth(S->mg_post))) return rc;
+        }
+        if (cur == own) held[own] = true;                 // adopt() releases it again
+        *result = cur;
+        return FS_OK;
+    }
+
     // ---- project (simulation.cpp:289-362) ----------------------------------------------
     int project() override
     {
@@ -667,7 +721,8 @@ struct Engine : EngineBase {
         // must become the neighbours' freshly zeroed planes before the first sweep reads them.
         if ((rc = halo(arr[slot[FS_PRESSURE]]))) return rc;
         int res;
-        rc = solve(0, slot[FS_PRESSURE], slot[FS_DIVERGENCE], (T)1, (T)6, S->acc, &res);   // :320
+        if (S->solver == FS_SOLVER_MG) rc = multigrid_pressure_solve(&res);
+        else rc = solve(0, slot[FS_PRESSURE], slot[FS_DIVERGENCE], (T)1, (T)6, S->acc, &res);   // :320
         if (rc) return rc;
         adopt(FS_PRESSURE, res);
         {
@@ -1318,7 +1373,12 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         if (v == "jacobi") s->solver = FS_SOLVER_JACOBI;
         else if (v == "gs_lex") s->solver = FS_SOLVER_GS_LEX;
         else if (v == "rbsor") s->solver = FS_SOLVER_RBSOR;
-        else return fail(FS_EINVAL, "solver: jacobi | gs_lex | rbsor");
+        else if (v == "mg") s->solver = FS_SOLVER_MG;
+        else return fail(FS_EINVAL, "solver: jacobi | gs_lex | rbsor | mg");
+    } else if (k == "mg_cycles" || k == "mg_pre" || k == "mg_post" || k == "mg_coarse_iters") {
+        const int n = atoi(value);
+        if (n < (k == "mg_cycles" ? 0 : 1) || n > 1000) return fail(FS_EINVAL, "%s out of range", key);
+        (k == "mg_cycles" ? s->mg_cycles : k == "mg_pre" ? s->mg_pre : k == "mg_post" ? s->mg_post : s->mg_coarse) = n;
     } else if (k == "sor_omega") {
         const float om = (float)atof(value);
         if (!(om > 0.0f && om < 2.0f)) return fail(FS_EINVAL, "sor_omega must lie in (0, 2)");
@@ -1400,6 +1460,7 @@ int fs_get_int(fs_sim* s, const char* name, int* out)
     else if (n == "triple_plan") *out = s->eng ? s->eng->tuned_triple() : -1;
     else if (n == "two_sweep_fused") *out = (s->eng && s->eng->tuned_shape() >= 64) ? 1 : 0;   // 1: jacobi_fused_kernel<NL=2>, 0: jacobi_pair_kernel
     else if (n == "halo_depth") *out = s->eng ? s->eng->halo_depth() : 0;
+    else if (n == "mg_levels") *out = s->eng ? s->eng->multigrid_levels() : 0;          // levels of the last solver=mg solve, level 0 included
     else return fail(FS_EINVAL, "unknown int member '%s'", name);
     return FS_OK;
 }

@@ -1049,19 +1049,7 @@ void launch_set_bounds(hipStream_t st, const GridDesc& g, const SlabCtx& sc, T* 
 template void launch_set_bounds<float>(hipStream_t, const GridDesc&, const SlabCtx&, float*, const uint8_t*, int);
 template void launch_set_bounds<double>(hipStream_t, const GridDesc&, const SlabCtx&, double*, const uint8_t*, int);
 
-// Ghost-face writes shared by the per-cell kernels: `u` is the un-zeroed new value of
-// interior cell (x,y,z) of a field with boundary code b (simulation.cpp:187-215).
-template <class T>
-__device__ __forceinline__ void write_face_ghosts(const GridDesc& g, const SlabCtx& sc, T* q, long c, int x, int y,
-                                                  int z, T u, int b)
-{
-    if (x == 1) q[c - 1] = (b == 1) ? -u : u;
-    if (x == g.W) q[c + 1] = u;
-    if (y == 1) q[c - g.sy] = (b == 2) ? -u : u;
-    if (y == g.H) q[c + g.sy] = (b == 2) ? -u : u;
-    if (z == 1 && sc.lo_wall) q[c - g.sz] = (b == 3) ? -u : u;
-    if (z == g.D && sc.hi_wall) q[c + g.sz] = (b == 3) ? -u : u;
-}
+// (write_face_ghosts, the ghost-face writes of the per-cell kernels, lives in kernels_dev.h)
 
 // =====================================================================================
 // project, part 1: divergence + pressure reset + setBounds(0,div) + setBounds(0,p)

@@ -1,0 +1,358 @@
+// multigrid.hip -- coarse levels of the optional multigrid pressure solve (see multigrid.h).
+//
+// Every expression keeps the association order written in oracle/cpu_ref_mg.h; the build is
+// -ffp-contract=off, so the two agree bit for bit (tests/test_gpu_multigrid.py).  The kernels are
+// plain one-thread-per-cell passes: all coarse levels together hold 1/7 of the cells of level 0,
+// whose smoothing (jacobi_pair_kernel<.., RB>) and whose two transfer passes dominate a cycle.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "kernels_dev.h"
+#include "multigrid.h"
+
+namespace fs {
+
+namespace {
+
+constexpr int MG_MIN_DIM = 4;
+
+template <class T>
+__device__ __forceinline__ long lat(const MgLevel<T>& l, int x, int y, int z)
+{
+    return (long)x + (long)y * l.sy + (long)z * l.sz;
+}
+
+// ---- level-0 coefficients from the flag bytes (never stored) --------------------------------
+__device__ __forceinline__ bool in_range(const GridDesc& g, int x, int y, int z)
+{
+    return x >= 1 && x <= g.W && y >= 1 && y <= g.H && z >= 1 && z <= g.D;
+}
+__device__ __forceinline__ bool fluid0(const GridDesc& g, const uint8_t* flags, int x, int y, int z)
+{
+    return in_range(g, x, y, z) && !(flags[cell(g, x, y, z)] & F_SOLID);
+}
+__device__ __forceinline__ int solid0(const GridDesc& g, const uint8_t* flags, int x, int y, int z)
+{
+    return (in_range(g, x, y, z) && (flags[cell(g, x, y, z)] & F_SOLID)) ? 1 : 0;
+}
+template <class T>
+__device__ __forceinline__ T w0(const GridDesc& g, const uint8_t* flags, int x, int y, int z, int axis)
+{
+    const int xm = x - (axis == 0), ym = y - (axis == 1), zm = z - (axis == 2);
+    return (fluid0(g, flags, x, y, z) && fluid0(g, flags, xm, ym, zm)) ? (T)1 : (T)0;
+}
+template <class T>
+__device__ __forceinline__ T d0(const GridDesc& g, const uint8_t* flags, int x, int y, int z)
+{
+    if (!fluid0(g, flags, x, y, z)) return (T)0;
+    return (T)(solid0(g, flags, x + 1, y, z) + solid0(g, flags, x - 1, y, z) + solid0(g, flags, x, y + 1, z) +
+               solid0(g, flags, x, y - 1, z) + solid0(g, flags, x, y, z + 1) + solid0(g, flags, x, y, z - 1));
+}
+
+// Coefficients of level c from the level below: stored level f, or (FROM0) level 0's flag bytes.
+template <class T, bool FROM0>
+__global__ __launch_bounds__(256) void mg_coarsen_kernel(GridDesc g, const uint8_t* __restrict__ flags, MgLevel<T> f, MgLevel<T> c)
+{
+    const int X = 1 + blockIdx.x * 64 + threadIdx.x, Y = 1 + blockIdx.y * 4 + threadIdx.y, Z = 1 + blockIdx.z;
+    if (X > c.W + 1 || Y > c.H + 1 || Z > c.D + 1) return;
+    const long C = lat(c, X, Y, Z);
+    const int x = 2 * X - 1, y = 2 * Y - 1, z = 2 * Z - 1;      // first child
+    const T q = (T)0.25, hf = (T)0.5;
+    auto FW = [&](int axis, int xx, int yy, int zz) -> T {
+        if constexpr (FROM0) return w0<T>(g, flags, xx, yy, zz, axis);
+        else return (axis == 0 ? f.wx : axis == 1 ? f.wy : f.wz)[lat(f, xx, yy, zz)];
+    };
+    auto FD = [&](int xx, int yy, int zz) -> T {
+        if constexpr (FROM0) return d0<T>(g, flags, xx, yy, zz);
+        else return f.d[lat(f, xx, yy, zz)];
+    };
+    if (Y <= c.H && Z <= c.D) c.wx[C] = q * (((FW(0, x, y, z) + FW(0, x, y + 1, z)) + FW(0, x, y, z + 1)) + FW(0, x, y + 1, z + 1));
+    if (X <= c.W && Z <= c.D) c.wy[C] = q * (((FW(1, x, y, z) + FW(1, x + 1, y, z)) + FW(1, x, y, z + 1)) + FW(1, x + 1, y, z + 1));
+    if (X <= c.W && Y <= c.H) c.wz[C] = q * (((FW(2, x, y, z) + FW(2, x + 1, y, z)) + FW(2, x, y + 1, z)) + FW(2, x + 1, y + 1, z));
+    if (X <= c.W && Y <= c.H && Z <= c.D)
+        c.d[C] = hf * (((((((FD(x, y, z) + FD(x + 1, y, z)) + FD(x, y + 1, z)) + FD(x + 1, y + 1, z)) + FD(x, y, z + 1)) +
+                         FD(x + 1, y, z + 1)) + FD(x, y + 1, z + 1)) + FD(x + 1, y + 1, z + 1));
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void mg_diag_kernel(MgLevel<T> c)
+{
+    const int X = 1 + blockIdx.x * 64 + threadIdx.x, Y = 1 + blockIdx.y * 4 + threadIdx.y, Z = 1 + blockIdx.z;
+    if (X > c.W || Y > c.H) return;
+    const long C = lat(c, X, Y, Z);
+    c.dg[C] = (((((c.wx[C] + c.wx[C + 1]) + c.wy[C]) + c.wy[C + c.sy]) + c.wz[C]) + c.wz[C + c.sz]) + c.d[C];
+}
+
+template <class T>
+__device__ __forceinline__ T weighted_neighbours(const MgLevel<T>& l, long c)
+{
+    const T* e = l.e;
+    return ((((l.wx[c] * e[c - 1] + l.wx[c + 1] * e[c + 1]) + l.wy[c] * e[c - l.sy]) + l.wy[c + l.sy] * e[c + l.sy]) +
+            l.wz[c] * e[c - l.sz]) + l.wz[c + l.sz] * e[c + l.sz];
+}
+
+// one colour of a red-black Gauss-Seidel iteration: the cells with (x + y + z) & 1 == colour
+template <class T>
+__global__ __launch_bounds__(256) void mg_smooth_kernel(MgLevel<T> l, int colour)
+{
+    const int y = 1 + blockIdx.y * 4 + threadIdx.y, z = 1 + blockIdx.z;
+    const int x = 1 + 2 * (blockIdx.x * 64 + threadIdx.x) + (((y + z + colour) & 1) ? 0 : 1);
+    if (x > l.W || y > l.H) return;
+    const long c = lat(l, x, y, z);
+    const T dg = l.dg[c];
+    if (!(dg > (T)0)) return;
+    l.e[c] = (l.b[c] + weighted_neighbours(l, c)) / dg;
+}
+
+template <class T>
+__device__ __forceinline__ T residual_at(const MgLevel<T>& l, long c)
+{
+    const T dg = l.dg[c];
+    if (!(dg > (T)0)) return (T)0;
+    return (l.b[c] + weighted_neighbours(l, c)) - dg * l.e[c];
+}
+
+// right-hand side of level c = 1/2 * sum of the eight children's residuals on level f; e_c = 0
+template <class T>
+__global__ __launch_bounds__(256) void mg_restrict_kernel(MgLevel<T> f, MgLevel<T> c)
+{
+    const int X = 1 + blockIdx.x * 64 + threadIdx.x, Y = 1 + blockIdx.y * 4 + threadIdx.y, Z = 1 + blockIdx.z;
+    if (X > c.W || Y > c.H) return;
+    const long C = lat(c, X, Y, Z);
+    const int x = 2 * X - 1, y = 2 * Y - 1, z = 2 * Z - 1;
+    T r = residual_at(f, lat(f, x, y, z));
+    r = r + residual_at(f, lat(f, x + 1, y, z));
+    r = r + residual_at(f, lat(f, x, y + 1, z));
+    r = r + residual_at(f, lat(f, x + 1, y + 1, z));
+    r = r + residual_at(f, lat(f, x, y, z + 1));
+    r = r + residual_at(f, lat(f, x + 1, y, z + 1));
+    r = r + residual_at(f, lat(f, x, y + 1, z + 1));
+    r = r + residual_at(f, lat(f, x + 1, y + 1, z + 1));
+    c.b[C] = (c.dg[C] > (T)0) ? (T)0.5 * r : (T)0;
+    c.e[C] = (T)0;
+}
+
+// level 0: residual of the reference's fixed point, sum order of simulation.cpp:264-268
+template <class T>
+__device__ __forceinline__ T residual0_at(const GridDesc& g, const uint8_t* flags, const T* p, const T* rhs, int x, int y, int z)
+{
+    const long c = cell(g, x, y, z);
+    if (flags[c] & F_SOLID) return (T)0;
+    const T nb = p[c + 1] + p[c - 1] + p[c + g.sy] + p[c - g.sy] + p[c + g.sz] + p[c - g.sz];
+    return (rhs[c] + nb) - (T)6 * p[c];
+}
+
+// One thread per FINE cell column pair: a lane computes the residuals of its x at the four (y, z) children of coarse
+// row (Y, Z) -- every load is a coalesced row segment -- and the even lane (x odd: the first child) adds its odd
+// neighbour's by wave shuffle, in the order the oracle sums the eight children.
+template <class T>
+__global__ __launch_bounds__(256) void mg_restrict0_kernel(GridDesc g, const uint8_t* __restrict__ flags, const T* __restrict__ p,
+                                                            const T* __restrict__ rhs, MgLevel<T> c)
+{
+    const int x = 1 + blockIdx.x * 64 + threadIdx.x;
+    const int Y = 1 + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y), Z = 1 + blockIdx.z;
+    if (Y > c.H) return;                                  // wave-uniform
+    const int y = 2 * Y - 1, z = 2 * Z - 1;
+    const bool on = x <= g.W;
+    T r00 = (T)0, r10 = (T)0, r01 = (T)0, r11 = (T)0;     // (dy, dz)
+    if (on) {
+        r00 = residual0_at(g, flags, p, rhs, x, y, z);
+        r10 = residual0_at(g, flags, p, rhs, x, y + 1, z);
+        r01 = residual0_at(g, flags, p, rhs, x, y, z + 1);
+        r11 = residual0_at(g, flags, p, rhs, x, y + 1, z + 1);
+    }
+    const T n00 = __shfl_down(r00, 1), n10 = __shfl_down(r10, 1), n01 = __shfl_down(r01, 1), n11 = __shfl_down(r11, 1);
+    if (!on || (threadIdx.x & 1)) return;
+    T r = r00;
+    r = r + n00;
+    r = r + r10;
+    r = r + n10;
+    r = r + r01;
+    r = r + n01;
+    r = r + r11;
+    r = r + n11;
+    const long C = lat(c, (x + 1) >> 1, Y, Z);
+    c.b[C] = (c.dg[C] > (T)0) ? (T)0.5 * r : (T)0;
+    c.e[C] = (T)0;
+}
+
+// trilinear interpolation of level c's correction at fine cell (x, y, z); neighbour index clamped at the walls
+template <class T>
+__device__ __forceinline__ T interp(const MgLevel<T>& c, int x, int y, int z)
+{
+    const int X = (x + 1) >> 1, Y = (y + 1) >> 1, Z = (z + 1) >> 1;
+    const int Xn = min(max((x & 1) ? X - 1 : X + 1, 1), c.W);
+    const int Yn = min(max((y & 1) ? Y - 1 : Y + 1, 1), c.H);
+    const int Zn = min(max((z & 1) ? Z - 1 : Z + 1, 1), c.D);
+    const T a = (T)0.75, q = (T)0.25;
+    const T* e = c.e;
+    const T x00 = a * e[lat(c, X, Y, Z)] + q * e[lat(c, Xn, Y, Z)];
+    const T x10 = a * e[lat(c, X, Yn, Z)] + q * e[lat(c, Xn, Yn, Z)];
+    const T x01 = a * e[lat(c, X, Y, Zn)] + q * e[lat(c, Xn, Y, Zn)];
+    const T x11 = a * e[lat(c, X, Yn, Zn)] + q * e[lat(c, Xn, Yn, Zn)];
+    const T y0 = a * x00 + q * x10;
+    const T y1 = a * x01 + q * x11;
+    return a * y0 + q * y1;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void mg_prolong_kernel(MgLevel<T> c, MgLevel<T> f)
+{
+    const int x = 1 + blockIdx.x * 64 + threadIdx.x, y = 1 + blockIdx.y * 4 + threadIdx.y, z = 1 + blockIdx.z;
+    if (x > f.W || y > f.H) return;
+    const long i = lat(f, x, y, z);
+    if (f.dg[i] > (T)0) f.e[i] = f.e[i] + interp(c, x, y, z);
+}
+
+// level 0: p += correction at the cells that are not solid, then setBounds(0, p) (solids already hold 0).
+// Four x-consecutive cells per lane (one 16-byte load / store of p, one flag word): they share the coarse columns
+// X-1 .. X+2 of four coarse rows.
+template <class T>
+__global__ __launch_bounds__(256) void mg_prolong0_kernel(MgLevel<T> c, GridDesc g, SlabCtx sc, const uint8_t* __restrict__ flags,
+                                                           T* __restrict__ p)
+{
+    const int x0 = 1 + 4 * (blockIdx.x * 64 + threadIdx.x);
+    const int y = 1 + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y), z = 1 + blockIdx.z;
+    if (x0 > g.W || y > g.H) return;
+    const long i = cell(g, x0, y, z);
+    const int X = (x0 + 1) >> 1, Y = (y + 1) >> 1, Z = (z + 1) >> 1;
+    const int Yn = min(max((y & 1) ? Y - 1 : Y + 1, 1), c.H), Zn = min(max((z & 1) ? Z - 1 : Z + 1, 1), c.D);
+    // coarse columns of the four cells: own (X, X, X+1, X+1), neighbour (X-1, X+1, X, X+2), clamped at the walls
+    const int Xm = max(X - 1, 1), X1 = min(X + 1, c.W), X2 = min(X + 2, c.W);
+    const T a = (T)0.75, q = (T)0.25;
+    T row[4][4];                                          // [(Y,Z), (Yn,Z), (Y,Zn), (Yn,Zn)][column Xm, X, X1, X2]
+    {
+        const long rows[4] = { lat(c, 0, Y, Z), lat(c, 0, Yn, Z), lat(c, 0, Y, Zn), lat(c, 0, Yn, Zn) };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            row[k][0] = c.e[rows[k] + Xm];
+            row[k][1] = c.e[rows[k] + X];
+            row[k][2] = c.e[rows[k] + X1];
+            row[k][3] = c.e[rows[k] + X2];
+        }
+    }
+    V4<T> v = *reinterpret_cast<const V4<T>*>(p + i);
+    const unsigned fw = *reinterpret_cast<const unsigned*>(flags + i);
+    T u[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int own = 1 + (e >> 1);                     // column index in row[][]: cells 0, 1 -> X; cells 2, 3 -> X+1
+        // the neighbour column of an odd x (cells 0, 2) is the one below, of an even x the one above; the clamp of the
+        // oracle's index (X-1 -> 1, X+1 -> W) is already in Xm / X1 / X2
+        const int nbr = (e & 1) ? own + 1 : own - 1;
+        const T x00 = a * row[0][own] + q * row[0][nbr];
+        const T x10 = a * row[1][own] + q * row[1][nbr];
+        const T x01 = a * row[2][own] + q * row[2][nbr];
+        const T x11 = a * row[3][own] + q * row[3][nbr];
+        const T y0 = a * x00 + q * x10;
+        const T y1 = a * x01 + q * x11;
+        const T corr = a * y0 + q * y1;
+        const bool solid = ((fw >> (8 * e)) & F_SOLID) != 0;
+        u[e] = (x0 + e <= g.W) ? (solid ? v.e[e] : v.e[e] + corr) : (T)0;
+    }
+    // setBounds(0, p): ghost faces mirror the (un-zeroed) interior values; ghost edges and row padding stay 0
+    V4<T> o, face;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int x = x0 + e;
+        o.e[e] = (x <= g.W) ? u[e] : ((x == g.W + 1) ? u[e - (e > 0 ? 1 : 0)] : (T)0);
+        face.e[e] = (x <= g.W) ? u[e] : (T)0;
+    }
+    *reinterpret_cast<V4<T>*>(p + i) = o;
+    if (x0 == 1) p[i - 1] = u[0];
+    if (x0 + 3 == g.W) p[i + 4] = u[3];                   // the ghost x = W+1 when W is a multiple of 4
+    if (y == 1) *reinterpret_cast<V4<T>*>(p + i - g.sy) = face;
+    if (y == g.H) *reinterpret_cast<V4<T>*>(p + i + g.sy) = face;
+    if (z == 1 && sc.lo_wall) *reinterpret_cast<V4<T>*>(p + i - g.sz) = face;
+    if (z == g.D && sc.hi_wall) *reinterpret_cast<V4<T>*>(p + i + g.sz) = face;
+}
+
+inline dim3 blk() { return dim3(64, 4, 1); }
+inline dim3 grd(int nx, int ny, int nz) { return dim3((nx + 63) / 64, (ny + 3) / 4, nz); }
+
+}  // namespace
+
+template <class T>
+void Multigrid<T>::release()
+{
+    if (pool) hipFree(pool);
+    pool = nullptr;
+    lv.clear();
+    W0 = H0 = D0 = 0;
+}
+
+template <class T>
+hipError_t Multigrid<T>::build(hipStream_t st, const GridDesc& g, const uint8_t* flags)
+{
+    if (g.W != W0 || g.H != H0 || g.D != D0 || lv.empty()) {
+        release();
+        W0 = g.W; H0 = g.H; D0 = g.D;
+        lv.push_back(MgLevel<T>{g.W, g.H, g.D, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+        int W = g.W, H = g.H, D = g.D;
+        size_t total = 0;
+        while (W % 2 == 0 && H % 2 == 0 && D % 2 == 0 && W / 2 >= MG_MIN_DIM && H / 2 >= MG_MIN_DIM && D / 2 >= MG_MIN_DIM) {
+            W /= 2; H /= 2; D /= 2;
+            MgLevel<T> l{};
+            l.W = W; l.H = H; l.D = D;
+            l.sy = W + 2;
+            l.sz = l.sy * (H + 2);
+            l.n = l.sz * (D + 2);
+            total += 7 * (size_t)l.n;
+            lv.push_back(l);
+        }
+        if (total) {
+            hipError_t e = hipMalloc((void**)&pool, total * sizeof(T));
+            if (e != hipSuccess) { lv.clear(); W0 = 0; return e; }
+            T* q = pool;
+            for (size_t i = 1; i < lv.size(); ++i) {
+                MgLevel<T>& l = lv[i];
+                T** arrs[] = { &l.wx, &l.wy, &l.wz, &l.d, &l.dg, &l.e, &l.b };
+                for (T** a : arrs) { *a = q; q += l.n; }
+            }
+        }
+    }
+    if (pool) {
+        size_t total = 0;
+        for (size_t i = 1; i < lv.size(); ++i) total += 7 * (size_t)lv[i].n;
+        hipError_t e = hipMemsetAsync(pool, 0, total * sizeof(T), st);     // ghosts, dead cells and wall faces stay 0
+        if (e != hipSuccess) return e;
+    }
+    for (size_t i = 1; i < lv.size(); ++i) {
+        MgLevel<T>& c = lv[i];
+        if (i == 1)
+            hipLaunchKernelGGL((mg_coarsen_kernel<T, true>), grd(c.W + 1, c.H + 1, c.D + 1), blk(), 0, st, g, flags, lv[0], c);
+        else
+            hipLaunchKernelGGL((mg_coarsen_kernel<T, false>), grd(c.W + 1, c.H + 1, c.D + 1), blk(), 0, st, g, flags, lv[i - 1], c);
+        hipLaunchKernelGGL((mg_diag_kernel<T>), grd(c.W, c.H, c.D), blk(), 0, st, c);
+    }
+    return hipGetLastError();
+}
+
+template <class T>
+void Multigrid<T>::coarse_correction(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, T* p, const T* rhs,
+                                     int pre, int post, int coarse_iters)
+{
+    const int nl = levels();
+    if (nl < 2) return;
+    auto smooth = [&](MgLevel<T>& l, int n) {
+        for (int it = 0; it < n; ++it)
+            for (int colour = 0; colour < 2; ++colour)
+                hipLaunchKernelGGL((mg_smooth_kernel<T>), grd((l.W + 1) / 2, l.H, l.D), blk(), 0, st, l, colour);
+    };
+    hipLaunchKernelGGL((mg_restrict0_kernel<T>), grd(g.W, lv[1].H, lv[1].D), blk(), 0, st, g, flags, p, rhs, lv[1]);
+    for (int l = 1; l < nl - 1; ++l) {                    // down
+        smooth(lv[l], pre);
+        hipLaunchKernelGGL((mg_restrict_kernel<T>), grd(lv[l + 1].W, lv[l + 1].H, lv[l + 1].D), blk(), 0, st, lv[l], lv[l + 1]);
+    }
+    smooth(lv[nl - 1], coarse_iters);
+    for (int l = nl - 2; l >= 1; --l) {                   // up
+        hipLaunchKernelGGL((mg_prolong_kernel<T>), grd(lv[l].W, lv[l].H, lv[l].D), blk(), 0, st, lv[l + 1], lv[l]);
+        smooth(lv[l], post);
+    }
+    hipLaunchKernelGGL((mg_prolong0_kernel<T>), grd((g.W + 3) / 4, g.H, g.D), blk(), 0, st, lv[1], g, sc, flags, p);
+}
+
+template struct Multigrid<float>;
+template struct Multigrid<double>;
+
+}  // namespace fs

@@ -51,9 +51,14 @@ enum {
 enum {
     FS_SOLVER_JACOBI = 0,  /* ping-pong Jacobi, any grid, multi-GPU capable (default) */
     FS_SOLVER_GS_LEX = 1,  /* the reference's in-place sweep in its one-thread order; verification mode */
-    FS_SOLVER_RBSOR = 2    /* NOT the reference's arithmetic: red-black successive over-relaxation, `acc`
+    FS_SOLVER_RBSOR = 2,   /* NOT the reference's arithmetic: red-black successive over-relaxation, `acc`
                             * iterations (even x+y+z cells, then odd, setBounds after each half), relaxation
                             * factor "sor_omega"; converges far faster per iteration; SURVEY.md 8f rank 4 */
+    FS_SOLVER_MG = 3       /* NOT the reference's arithmetic: the projection's pressure equation (simulation.cpp:320) is
+                            * solved by "mg_cycles" multigrid V-cycles instead of `acc` relaxation sweeps (2x2x2
+                            * cell-centred coarsening, red-black smoothing, obstacle-aware coarse operators; defined in
+                            * oracle/cpu_ref_mg.h); every other solve (diffusion, fs_linear_solver) runs Jacobi.  Single
+                            * GPU; grids whose extents cannot be halved get no coarse levels.  SURVEY.md 8f rank 4 */
 };
 
 /* ---- construction -------------------------------------------------------------- */
@@ -100,6 +105,8 @@ int fs_destroy(fs_sim* s);
  *                 two-sweep kernels (jacobi_pair_kernel / jacobi_fused_kernel<NL=2>) runs those passes;
  *   "advect_kernels" "cell" (default: one thread per cell) | "celltab" (the same reading clamped traces from the
  *                 column tables) | "row" (four cells per lane, clamp tables); all bit-identical, none faster by > 5 %;
+ *   "mg_cycles" (default 8), "mg_pre", "mg_post" (smoothing steps before / after the coarse correction, default 1),
+ *                 "mg_coarse_iters" (iterations on the coarsest level, default 30): solver "mg" only;
  *   "wall_free"   "auto" (default) | "0" | "1": whether workgroups of the three-sweep kernel that touch no wall run its
  *                 wall-free second body (auto: when a launch has more than 256 workgroups);
  *   "sweep_ry" "sweep_zc" "sweep_blocks" "pair_zc" "pair_shape" "project_kernels" "fuse_advect"

@@ -14,8 +14,9 @@
  * them bit for bit.  tests/test_oracle_vs_ref.py repeats that live against libref.so
  * whenever it is present.
  *
- * Solver modes (a third, CR_RBSOR, is the build's own optional red-black SOR and has no
- * counterpart in the reference; see relax()):
+ * Solver modes (two more, CR_RBSOR and CR_MG, are the build's own optional solvers and have no
+ * counterpart in the reference; see relax() and cpu_ref_mg.h; under CR_MG only the projection's
+ * pressure solve changes, every other solve is CR_JACOBI):
  *   CR_GS_LEX  the reference's in-place sweep in its own loop order (x outer, y, z inner;
  *              simulation.cpp:258-270), i.e. the reference at one thread.
  *   CR_JACOBI  the same update reading all six neighbours from the previous iterate
@@ -45,7 +46,7 @@ typedef CR_REAL real;
 /* cube root in the field precision: cbrtf for float (std::cbrt(float), simulation.cpp:295) */
 #define CR_CBRT(v) (sizeof(real) == sizeof(float) ? (real)cbrtf((float)(v)) : (real)cbrt((double)(v)))
 
-enum { CR_GS_LEX = 0, CR_JACOBI = 1, CR_RBSOR = 2 };
+enum { CR_GS_LEX = 0, CR_JACOBI = 1, CR_RBSOR = 2, CR_MG = 3 };
 enum { CR_DENS = 0, CR_VX, CR_VY, CR_VZ, CR_OBS, CR_P, CR_DIV, CR_VX0, CR_VY0, CR_VZ0, CR_BUF, CR_NFIELDS };
 
 typedef struct cr_sim {
@@ -54,6 +55,7 @@ typedef struct cr_sim {
     float dt, diff, visc;
     int solver;
     float omega;              /* CR_RBSOR only */
+    int mg_cycles, mg_pre, mg_post, mg_coarse;   /* CR_MG only: V-cycles per pressure solve, smoothing steps, coarsest-level iterations */
     size_t n;                 /* padded cell count (simulation.cpp:35) */
     size_t sy, sz;            /* strides: idx = x + y*sy + z*sz (simulation.h:9) */
     real* f[CR_NFIELDS];
@@ -73,6 +75,7 @@ cr_sim* cr_create(int w, int h, int d, int iter, int speed, float dt, float diff
     s->dt = dt; s->diff = diff; s->visc = visc;
     s->solver = CR_GS_LEX;
     s->omega = 1.0f;
+    s->mg_cycles = 8; s->mg_pre = 1; s->mg_post = 1; s->mg_coarse = 30;
     s->sy = (size_t)w + 2;
     s->sz = s->sy * ((size_t)h + 2);
     s->n = s->sz * ((size_t)d + 2);
@@ -94,6 +97,7 @@ void cr_destroy(cr_sim* s)
 
 void cr_set_solver(cr_sim* s, int mode) { s->solver = mode; }
 void cr_set_omega(cr_sim* s, float omega) { s->omega = omega; }
+void cr_set_mg(cr_sim* s, int cycles, int pre, int post, int coarse) { s->mg_cycles = cycles; s->mg_pre = pre; s->mg_post = post; s->mg_coarse = coarse; }
 int cr_real_bytes(void) { return (int)sizeof(real); }
 long cr_size(cr_sim* s) { return (long)s->n; }
 
@@ -176,6 +180,31 @@ static void enforce_bounds(cr_sim* s, int b, real* q)
             }
 }
 
+/* NOT in the reference: the build's optional red-black iteration (solver mode CR_RBSOR, SURVEY.md 8f
+ * rank 4; also the level-0 smoother of CR_MG), defined here.  One iteration = the cells with even
+ * x+y+z, then those with odd x+y+z, each half followed by the reference's setBounds; a cell moves
+ * from its value q towards the reference's update r by q + omega*(r - q).  Cells of one colour do not
+ * neighbour each other, so the in-place loop has no ordering freedom. */
+static void rb_iterations(cr_sim* s, int b, real* q, const real* rhs, real a, real inv_c, real om, int n)
+{
+    const int W = s->W, H = s->H, D = s->D;
+    const size_t sy = s->sy, sz = s->sz;
+    for (int it = 0; it < n; ++it)
+        for (int colour = 0; colour < 2; ++colour) {
+#pragma omp parallel for collapse(2) schedule(static)
+            for (int z = 1; z <= D; ++z)
+                for (int y = 1; y <= H; ++y)
+                    for (int x = 1; x <= W; ++x) {
+                        if (((x + y + z) & 1) != colour) continue;
+                        size_t c = AT(s, x, y, z);
+                        real nb = q[c + 1] + q[c - 1] + q[c + sy] + q[c - sy] + q[c + sz] + q[c - sz];
+                        real r = (rhs[c] + a * nb) * inv_c;
+                        q[c] = q[c] + om * (r - q[c]);
+                    }
+            enforce_bounds(s, b, q);
+        }
+}
+
 /* ------------------------------------------------------------------ linear solver
  * simulation.cpp:251-273.  Every interior cell is updated, solids included; the sum is
  * taken in the order x+1, x-1, y+1, y-1, z+1, z-1 and scaled by a reciprocal. */
@@ -185,29 +214,11 @@ static void relax(cr_sim* s, int b, real* q, const real* rhs, real a, real c)
     const size_t sy = s->sy, sz = s->sz;
     const real inv_c = (real)1 / c;                    /* :257 */
 
+    if (s->solver == CR_RBSOR) {
+        rb_iterations(s, b, q, rhs, a, inv_c, (real)s->omega, s->sweeps);
+        return;
+    }
     for (int it = 0; it < s->sweeps; ++it) {
-        if (s->solver == CR_RBSOR) {
-            /* NOT in the reference: the build's optional solver mode, defined
-             * here.  One iteration = the cells with even x+y+z, then those with odd x+y+z, each
-             * half followed by the reference's setBounds; a cell moves from its value q towards
-             * the reference's update r by q + omega*(r - q).  Cells of one colour do not neighbour
-             * each other, so the in-place loop has no ordering freedom. */
-            const real om = (real)s->omega;
-            for (int colour = 0; colour < 2; ++colour) {
-#pragma omp parallel for collapse(2) schedule(static)
-                for (int z = 1; z <= D; ++z)
-                    for (int y = 1; y <= H; ++y)
-                        for (int x = 1; x <= W; ++x) {
-                            if (((x + y + z) & 1) != colour) continue;
-                            size_t c = AT(s, x, y, z);
-                            real nb = q[c + 1] + q[c - 1] + q[c + sy] + q[c - sy] + q[c + sz] + q[c - sz];
-                            real r = (rhs[c] + a * nb) * inv_c;
-                            q[c] = q[c] + om * (r - q[c]);
-                        }
-                enforce_bounds(s, b, q);
-            }
-            continue;
-        }
         if (s->solver == CR_GS_LEX) {
             /* reference traversal: x outermost, z innermost, updated in place (:260-262).
              * With >1 thread this is the same chunked race the reference has. */
@@ -237,6 +248,8 @@ static void relax(cr_sim* s, int b, real* q, const real* rhs, real a, real c)
         enforce_bounds(s, b, q);                       /* :271 */
     }
 }
+
+#include "cpu_ref_mg.h"
 
 /* simulation.cpp:278-284: a = dt*diff*W*H*D evaluated left to right in float */
 static void spread(cr_sim* s, int b, real* q, const real* rhs)
@@ -276,7 +289,8 @@ static void make_solenoidal(cr_sim* s)
 
     enforce_bounds(s, 0, dv);
     enforce_bounds(s, 0, p);
-    relax(s, 0, p, dv, (real)1, (real)6);
+    if (s->solver == CR_MG) mg_solve(s, p, dv);        /* the build's own mode, cpu_ref_mg.h */
+    else relax(s, 0, p, dv, (real)1, (real)6);         /* :320 */
 
     const real two_h = (real)2 * h;
 #pragma omp parallel for collapse(2) schedule(static)

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DENS, VX, VY, VZ, OBS, P, DIV, VX0, VY0, VZ0, BUF = range(11)
 FIELD_NAMES = ["dens", "v_x", "v_y", "v_z", "obs", "pressure", "divergence",
                "v_x_prev", "v_y_prev", "v_z_prev", "buffer"]
-GS_LEX, JACOBI, RBSOR = 0, 1, 2
+GS_LEX, JACOBI, RBSOR, MG = 0, 1, 2, 3
 
 
 def build(force=False):
@@ -144,11 +144,13 @@ class _Sim:
 
 
 class Oracle(_Sim):
-    """The C restatement.  solver = GS_LEX (reference order), JACOBI, or RBSOR (the build's own
-    optional red-black SOR, relaxation factor `omega`; not in the reference)."""
+    """The C restatement.  solver = GS_LEX (reference order), JACOBI, RBSOR (the build's own
+    optional red-black SOR, relaxation factor `omega`; not in the reference) or MG (the build's own
+    multigrid pressure solve, oracle/cpu_ref_mg.h; `mg` = (V-cycles, pre-, post-smoothing steps,
+    coarsest-level iterations); not in the reference)."""
     prefix = "cr_"
 
-    def __init__(self, w, h, d, solver=GS_LEX, fp64=False, threads=None, omega=1.0, **kw):
+    def __init__(self, w, h, d, solver=GS_LEX, fp64=False, threads=None, omega=1.0, mg=None, **kw):
         lib = _load("libcpu_ref64.so" if fp64 else "libcpu_ref.so")
         self.dtype = np.float64 if fp64 else np.float32
         super().__init__(lib, w, h, d, **kw)
@@ -157,6 +159,8 @@ class Oracle(_Sim):
         self._call("set_solver", C.c_int(solver))
         if solver == RBSOR:
             self._call("set_omega", C.c_float(omega))
+        if mg is not None:
+            self._call("set_mg", *(C.c_int(int(v)) for v in mg))
 
     def load_stl(self, path, scale=0.8, rot=(0.0, 0.0, 0.0), translate=(0.0, 0.0, 0.0), seed=1):
         return self._call("load_stl", C.c_char_p(os.fsencode(path)), C.c_float(scale),
