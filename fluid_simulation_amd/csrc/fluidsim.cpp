@@ -96,7 +96,7 @@ struct fs_sim {
     bool fp64 = false;
     int solver = FS_SOLVER_JACOBI;
     float omega = 1.0f;          // relaxation factor of solver=rbsor
-    int mg_cycles = 8, mg_pre = 1, mg_post = 1, mg_coarse = 30;   // solver=mg: V-cycles per pressure solve, smoothing steps, coarsest-level iterations
+    int mg_cycles = 4, mg_pre = 1, mg_post = 1, mg_coarse = 30;   // solver=mg: V-cycles per pressure solve, smoothing steps, coarsest-level iterations
     std::string dump_dir = "data";
     int dump_every = 1;
     unsigned voxel_seed = 1;
@@ -629,7 +629,13 @@ struct Engine : EngineBase {
         if (rc) return rc;
         if (S->solver == FS_SOLVER_GS_LEX && (rc = unalias(field))) return rc;
         int res;
-        rc = solve(b, slot[field], slot[prev], (T)a, (T)c, S->acc, &res);
+        if (S->solver == FS_SOLVER_MG && b == 0 && a == 1.0f && c == 6.0f) {
+            // the pressure equation's coefficients (:320): V-cycles; every other system (diffusion) is relaxed as under jacobi
+            if ((rc = unalias(field)) || (rc = unalias(prev))) return rc;
+            rc = multigrid_solve(field, prev, &res);
+        } else {
+            rc = solve(b, slot[field], slot[prev], (T)a, (T)c, S->acc, &res);
+        }
         if (rc) return rc;
         adopt(field, res);
         return FS_OK;
@@ -663,7 +669,7 @@ struct Engine : EngineBase {
     // equation of :320.  Level 0 is smoothed by red-black passes of the reference's update (the pair kernel), the coarse
     // levels live in multigrid.hip.  Single GPU.
     int multigrid_levels() const override { return mg.levels(); }
-    int multigrid_pressure_solve(int* result)
+    int multigrid_solve(int field, int prev, int* result)
     {
         if (S->comm.active()) return fail(FS_EINVAL, "solver=mg is single-GPU (z-slab runs use jacobi or rbsor)");
         if (S->mg_cycles > 0 && !fs::pair_supported<T>(S->tune, g, sc))
@@ -674,7 +680,8 @@ struct Engine : EngineBase {
             if (e != hipSuccess) return fail(FS_EHIP, "multigrid levels: %s", hipGetErrorString(e));
             mg_current = true;
         }
-        const int own = slot[FS_PRESSURE], rhs = slot[FS_DIVERGENCE];
+        const int own = slot[field], rhs = slot[prev];
+        if (own == rhs) return fail(FS_EINVAL, "solver=mg needs distinct field and prev arrays");
         int cur = own;
         auto smooth = [&](int n) -> int {
             if (n <= 0) return FS_OK;
@@ -721,7 +728,7 @@ struct Engine : EngineBase {
         // must become the neighbours' freshly zeroed planes before the first sweep reads them.
         if ((rc = halo(arr[slot[FS_PRESSURE]]))) return rc;
         int res;
-        if (S->solver == FS_SOLVER_MG) rc = multigrid_pressure_solve(&res);
+        if (S->solver == FS_SOLVER_MG) rc = multigrid_solve(FS_PRESSURE, FS_DIVERGENCE, &res);
         else rc = solve(0, slot[FS_PRESSURE], slot[FS_DIVERGENCE], (T)1, (T)6, S->acc, &res);   // :320
         if (rc) return rc;
         adopt(FS_PRESSURE, res);

@@ -267,6 +267,76 @@ __global__ __launch_bounds__(256) void mg_prolong0_kernel(MgLevel<T> c, GridDesc
     if (z == g.D && sc.hi_wall) *reinterpret_cast<V4<T>*>(p + i + g.sz) = face;
 }
 
+// The small levels (at most BOTTOM_CELLS cells each) as ONE launch of one workgroup: their launches would cost more than
+// their work (a 512^3 cycle has three such levels and 60 coarsest-level half-sweeps; 32^3 cells on one CU is already slower than its launches).  Same per-cell expressions as the
+// kernels above; __syncthreads() orders the phases (one workgroup: one CU, one L1).
+constexpr long BOTTOM_CELLS = 4096;
+constexpr int BOTTOM_MAX = 10;
+
+template <class T>
+struct MgBottom {
+    MgLevel<T> lv[BOTTOM_MAX];
+    int n, pre, post, coarse;
+};
+
+template <class T>
+__global__ __launch_bounds__(1024) void mg_bottom_kernel(MgBottom<T> B)
+{
+    const int tid = threadIdx.x;
+    auto smooth = [&](const MgLevel<T>& l, int n) {
+        const int hw = (l.W + 1) >> 1, cnt = hw * l.H * l.D;
+        for (int it = 0; it < n; ++it)
+            for (int colour = 0; colour < 2; ++colour) {
+                for (int j = tid; j < cnt; j += 1024) {
+                    const int y = 1 + (j / hw) % l.H, z = 1 + j / (hw * l.H);
+                    const int x = 1 + 2 * (j % hw) + (((y + z + colour) & 1) ? 0 : 1);
+                    if (x > l.W) continue;
+                    const long c = lat(l, x, y, z);
+                    const T dg = l.dg[c];
+                    if (dg > (T)0) l.e[c] = (l.b[c] + weighted_neighbours(l, c)) / dg;
+                }
+                __syncthreads();
+            }
+    };
+    auto restrict_to = [&](const MgLevel<T>& f, const MgLevel<T>& c) {
+        const int cnt = c.W * c.H * c.D;
+        for (int j = tid; j < cnt; j += 1024) {
+            const int X = 1 + j % c.W, Y = 1 + (j / c.W) % c.H, Z = 1 + j / (c.W * c.H);
+            const long C = lat(c, X, Y, Z);
+            const int x = 2 * X - 1, y = 2 * Y - 1, z = 2 * Z - 1;
+            T r = residual_at(f, lat(f, x, y, z));
+            r = r + residual_at(f, lat(f, x + 1, y, z));
+            r = r + residual_at(f, lat(f, x, y + 1, z));
+            r = r + residual_at(f, lat(f, x + 1, y + 1, z));
+            r = r + residual_at(f, lat(f, x, y, z + 1));
+            r = r + residual_at(f, lat(f, x + 1, y, z + 1));
+            r = r + residual_at(f, lat(f, x, y + 1, z + 1));
+            r = r + residual_at(f, lat(f, x + 1, y + 1, z + 1));
+            c.b[C] = (c.dg[C] > (T)0) ? (T)0.5 * r : (T)0;
+            c.e[C] = (T)0;
+        }
+        __syncthreads();
+    };
+    auto prolong_to = [&](const MgLevel<T>& c, const MgLevel<T>& f) {
+        const int cnt = f.W * f.H * f.D;
+        for (int j = tid; j < cnt; j += 1024) {
+            const int x = 1 + j % f.W, y = 1 + (j / f.W) % f.H, z = 1 + j / (f.W * f.H);
+            const long i = lat(f, x, y, z);
+            if (f.dg[i] > (T)0) f.e[i] = f.e[i] + interp(c, x, y, z);
+        }
+        __syncthreads();
+    };
+    for (int k = 0; k < B.n - 1; ++k) {
+        smooth(B.lv[k], B.pre);
+        restrict_to(B.lv[k], B.lv[k + 1]);
+    }
+    smooth(B.lv[B.n - 1], B.coarse);
+    for (int k = B.n - 2; k >= 0; --k) {
+        prolong_to(B.lv[k + 1], B.lv[k]);
+        smooth(B.lv[k], B.post);
+    }
+}
+
 inline dim3 blk() { return dim3(64, 4, 1); }
 inline dim3 grd(int nx, int ny, int nz) { return dim3((nx + 63) / 64, (ny + 3) / 4, nz); }
 
@@ -340,12 +410,24 @@ void Multigrid<T>::coarse_correction(hipStream_t st, const GridDesc& g, const Sl
                 hipLaunchKernelGGL((mg_smooth_kernel<T>), grd((l.W + 1) / 2, l.H, l.D), blk(), 0, st, l, colour);
     };
     hipLaunchKernelGGL((mg_restrict0_kernel<T>), grd(g.W, lv[1].H, lv[1].D), blk(), 0, st, g, flags, p, rhs, lv[1]);
-    for (int l = 1; l < nl - 1; ++l) {                    // down
+    int lb = nl;                                          // first level of the single-workgroup bottom
+    for (int l = 1; l < nl; ++l)
+        if ((long)lv[l].W * lv[l].H * lv[l].D <= BOTTOM_CELLS && nl - l <= BOTTOM_MAX) { lb = l; break; }
+    const int top = lb < nl - 1 ? lb : nl - 1;            // the level the launches below stop at
+    for (int l = 1; l < top; ++l) {                       // down
         smooth(lv[l], pre);
         hipLaunchKernelGGL((mg_restrict_kernel<T>), grd(lv[l + 1].W, lv[l + 1].H, lv[l + 1].D), blk(), 0, st, lv[l], lv[l + 1]);
     }
-    smooth(lv[nl - 1], coarse_iters);
-    for (int l = nl - 2; l >= 1; --l) {                   // up
+    if (lb < nl) {
+        MgBottom<T> B;
+        B.n = nl - lb;
+        for (int k = 0; k < B.n; ++k) B.lv[k] = lv[lb + k];
+        B.pre = pre; B.post = post; B.coarse = coarse_iters;
+        hipLaunchKernelGGL((mg_bottom_kernel<T>), dim3(1), dim3(1024), 0, st, B);
+    } else {
+        smooth(lv[nl - 1], coarse_iters);
+    }
+    for (int l = top - 1; l >= 1; --l) {                  // up
         hipLaunchKernelGGL((mg_prolong_kernel<T>), grd(lv[l].W, lv[l].H, lv[l].D), blk(), 0, st, lv[l + 1], lv[l]);
         smooth(lv[l], post);
     }

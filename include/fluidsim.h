@@ -57,7 +57,8 @@ enum {
     FS_SOLVER_MG = 3       /* NOT the reference's arithmetic: the projection's pressure equation (simulation.cpp:320) is
                             * solved by "mg_cycles" multigrid V-cycles instead of `acc` relaxation sweeps (2x2x2
                             * cell-centred coarsening, red-black smoothing, obstacle-aware coarse operators; defined in
-                            * oracle/cpu_ref_mg.h); every other solve (diffusion, fs_linear_solver) runs Jacobi.  Single
+                            * oracle/cpu_ref_mg.h); so does fs_linear_solver when called with that equation's coefficients
+                            * (b = 0, a = 1, c = 6); every other solve (diffusion) runs Jacobi.  Single
                             * GPU; grids whose extents cannot be halved get no coarse levels.  SURVEY.md 8f rank 4 */
 };
 
@@ -105,7 +106,7 @@ int fs_destroy(fs_sim* s);
  *                 two-sweep kernels (jacobi_pair_kernel / jacobi_fused_kernel<NL=2>) runs those passes;
  *   "advect_kernels" "cell" (default: one thread per cell) | "celltab" (the same reading clamped traces from the
  *                 column tables) | "row" (four cells per lane, clamp tables); all bit-identical, none faster by > 5 %;
- *   "mg_cycles" (default 8), "mg_pre", "mg_post" (smoothing steps before / after the coarse correction, default 1),
+ *   "mg_cycles" (default 4: about the time of the 80 sweeps of config 3, residual 24x smaller), "mg_pre", "mg_post" (smoothing steps before / after the coarse correction, default 1),
  *                 "mg_coarse_iters" (iterations on the coarsest level, default 30): solver "mg" only;
  *   "wall_free"   "auto" (default) | "0" | "1": whether workgroups of the three-sweep kernel that touch no wall run its
  *                 wall-free second body (auto: when a launch has more than 256 workgroups);

@@ -75,7 +75,7 @@ cr_sim* cr_create(int w, int h, int d, int iter, int speed, float dt, float diff
     s->dt = dt; s->diff = diff; s->visc = visc;
     s->solver = CR_GS_LEX;
     s->omega = 1.0f;
-    s->mg_cycles = 8; s->mg_pre = 1; s->mg_post = 1; s->mg_coarse = 30;
+    s->mg_cycles = 4; s->mg_pre = 1; s->mg_post = 1; s->mg_coarse = 30;
     s->sy = (size_t)w + 2;
     s->sz = s->sy * ((size_t)h + 2);
     s->n = s->sz * ((size_t)d + 2);
@@ -401,7 +401,11 @@ void cr_run_one(cr_sim* s)
 
 /* individual passes, for per-kernel parity tests */
 void cr_set_bounds(cr_sim* s, int b, int field) { enforce_bounds(s, b, s->f[field]); }
-void cr_linear_solver(cr_sim* s, int b, int field, int prev, float a, float c) { relax(s, b, s->f[field], s->f[prev], (real)a, (real)c); }
+void cr_linear_solver(cr_sim* s, int b, int field, int prev, float a, float c)
+{
+    if (s->solver == CR_MG && b == 0 && a == 1.0f && c == 6.0f) mg_solve(s, s->f[field], s->f[prev]);   /* the pressure equation's coefficients */
+    else relax(s, b, s->f[field], s->f[prev], (real)a, (real)c);
+}
 void cr_diffuse(cr_sim* s, int b, int field, int prev) { spread(s, b, s->f[field], s->f[prev]); }
 void cr_project(cr_sim* s) { make_solenoidal(s); }
 void cr_advect(cr_sim* s, int b, int field, int prev) { transport(s, b, s->f[field], s->f[prev]); }

@@ -67,13 +67,13 @@ def test_multigrid_steps_match_the_oracle_bit_for_bit(F, oracle_mod, shape, fp64
 
 @pytest.mark.parametrize("shape", [(64, 64, 64), (128, 64, 64), (96, 48, 80)])
 def test_multigrid_solves_the_reference_pressure_equation(F, shape):
-    """The projection under solver=mg leaves the reference's pressure equation solved: after the default 8 V-cycles the
+    """The projection under solver=mg leaves the reference's pressure equation solved: after 8 V-cycles the
     residual of the fixed point of simulation.cpp:263-271 is below 1e-3 of its initial value on a developed flow around
     a ball and a plate (measured: 2e-4 and less), where 80 Jacobi sweeps leave more than a tenth (measured: 0.5)."""
     W, H, D = shape
     m = tunnel_mask(W, H, D)
     res = {}
-    for solver, kw in (("mg", {}), ("jacobi", {})):
+    for solver, kw in (("mg", dict(mg_cycles=8)), ("jacobi", {})):
         sim = F.Simulation(W, H, D, 1, acc=80, solver=solver, quiet=1, **kw)
         sim.set_mask(m)
         for _ in range(3):
@@ -102,3 +102,26 @@ def test_multigrid_follows_obstacle_edits_and_is_refused_on_slabs(F, oracle_mod)
     slab.comm_init(0, 2, b"FSNULL:".ljust(128, b"\0"))
     with pytest.raises(F.FluidsimError):
         slab.run_one()
+
+
+def test_linear_solver_with_the_pressure_coefficients_runs_v_cycles(F, oracle_mod):
+    """fs_linear_solver(0, x, x0, 1, 6) under solver=mg is the multigrid solve (on any pair of fields); other
+    coefficients are relaxed as under jacobi.  Both against the oracle's cr_linear_solver."""
+    O = oracle_mod
+    W, H, D = 48, 32, 16
+    m = tunnel_mask(W, H, D)
+    sim = F.Simulation(W, H, D, 1, acc=6, solver="mg", quiet=1, mg_cycles=3)
+    ora = O.Oracle(W, H, D, solver=O.MG, threads=4, acc=6, mg=(3, 1, 1, 30))
+    rng = np.random.default_rng(11)
+    rhs = rng.standard_normal((D + 2, H + 2, W + 2)).astype(np.float32)
+    for x in (sim, ora):
+        x.set_mask(m)
+    sim.set(F.VY_PREV, rhs)
+    ora.set(O.VY0, rhs)
+    sim.linear_solver(0, F.BUFFER, F.VY_PREV, 1.0, 6.0)
+    ora.linear_solver(0, O.BUF, O.VY0, 1.0, 6.0)
+    assert bits_equal(sim.get(F.BUFFER), ora.get(O.BUF))
+    assert relative_residual(sim.get(F.BUFFER), rhs, m) < 0.05
+    sim.linear_solver(1, F.VX, F.VY_PREV, 0.3, 2.8)
+    ora.linear_solver(1, O.VX, O.VY0, 0.3, 2.8)
+    assert bits_equal(sim.get(F.VX), ora.get(O.VX))

@@ -1,0 +1,75 @@
+"""CPU checks of the oracle's own statement of the optional multigrid mode (oracle/cpu_ref_mg.h, CR_MG): it solves the
+reference's pressure equation -- the fixed point of linearSolver(0, p, div, 1, 6) + setBounds(0, p), simulation.cpp:263-271
+and :320 -- and leaves every other part of a step on the Jacobi path.  The mode has no counterpart in the reference (which
+only ever relaxes), so there is nothing to pin it to; the GPU implementation is compared with this file bit for bit in
+tests/test_gpu_multigrid.py."""
+import numpy as np
+import pytest
+
+from conftest import ball_mask
+
+
+def relative_residual(p, div, mask):
+    p = p.astype(np.float64)
+    div = div.astype(np.float64)
+    nb = p[1:-1, 1:-1, 2:] + p[1:-1, 1:-1, :-2] + p[1:-1, 2:, 1:-1] + p[1:-1, :-2, 1:-1] + p[2:, 1:-1, 1:-1] + p[:-2, 1:-1, 1:-1]
+    r = div[1:-1, 1:-1, 1:-1] + nb - 6.0 * p[1:-1, 1:-1, 1:-1]
+    live = ~mask[1:-1, 1:-1, 1:-1]
+    return float(np.linalg.norm(r[live]) / np.linalg.norm(div[1:-1, 1:-1, 1:-1][live]))
+
+
+def developed(O, W, H, D, mask, fp64, **kw):
+    ora = O.Oracle(W, H, D, fp64=fp64, threads=8, acc=10, **kw)
+    ora.set_mask(mask)
+    for _ in range(2):
+        ora.run_one()
+    return ora
+
+
+@pytest.mark.parametrize("shape,fp64", [((32, 32, 32), False), ((64, 32, 16), False), ((48, 24, 24), True)])
+def test_multigrid_mode_solves_the_pressure_equation(oracle_mod, shape, fp64):
+    O = oracle_mod
+    W, H, D = shape
+    mask = ball_mask(W, H, D, W / 3.0, H / 2.0, D / 2.0, min(W, H, D) / 5.0)
+    mask[D // 4:3 * D // 4, H // 4:3 * H // 4, 2 * W // 3] = True        # a plate one cell thick
+    mask[0] = mask[-1] = False
+    mask[:, 0] = mask[:, -1] = False
+    mask[:, :, 0] = mask[:, :, -1] = False
+    res = []
+    for cycles in (1, 2, 4, 8):
+        ora = developed(O, W, H, D, mask, fp64, solver=O.MG, mg=(cycles, 1, 1, 30))
+        ora.project()
+        res.append(relative_residual(ora.get(O.P), ora.get(O.DIV), mask))
+    jac = developed(O, W, H, D, mask, fp64, solver=O.JACOBI)
+    jac.project()                                                          # 10 sweeps, the same cost class as one cycle
+    rj = relative_residual(jac.get(O.P), jac.get(O.DIV), mask)
+    assert res[0] > res[1] > res[2] > res[3], res
+    assert res[3] < 2e-3, res                                              # measured: 1e-4 .. 5e-4
+    assert res[1] < rj, (res, rj)
+
+
+def test_multigrid_mode_without_coarse_levels_and_outside_the_projection(oracle_mod):
+    """A grid whose extents cannot be halved gets no coarse levels (the cycles are red-black iterations on the grid
+    itself); diffusion under CR_MG is the Jacobi path."""
+    O = oracle_mod
+    W, H, D = 15, 9, 7
+    mask = ball_mask(W, H, D, 5, 4, 3, 2.0)
+    a = O.Oracle(W, H, D, solver=O.MG, threads=4, acc=6, mg=(2, 1, 1, 3))
+    b = O.Oracle(W, H, D, solver=O.RBSOR, omega=1.0, threads=4, acc=6)
+    j = O.Oracle(W, H, D, solver=O.JACOBI, threads=4, acc=6)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((D + 2, H + 2, W + 2)).astype(np.float32)
+    for o in (a, b, j):
+        o.set_mask(mask)
+        for f in (O.VX, O.VY, O.VZ):
+            o.set(f, v)
+    a.project()
+    b.project()                                                            # 6 red-black iterations = 2 cycles x 3
+    assert a.get(O.P).tobytes() == b.get(O.P).tobytes()
+    a.diffuse(1, O.VX, O.VX0)
+    j.set(O.VX, a.get(O.VX))                                               # (diffuse wrote it; restart both from one state)
+    a.set(O.VX0, v)
+    j.set(O.VX0, v)
+    a.diffuse(1, O.VX, O.VX0)
+    j.diffuse(1, O.VX, O.VX0)
+    assert a.get(O.VX).tobytes() == j.get(O.VX).tobytes()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """solver=mg against solver=jacobi on the benchmark workloads, one box, one process: ms per step, ms per projection
 family, and the relative residual of the pressure equation each leaves (simulation.cpp:263-271's fixed point).
-python tools/mg_time.py [c2|c3] [cycles]"""
+python tools/mg_time.py [c2|c3] [cycles]   (no cycles argument: 2, 4 and 8)"""
 import json
 import os
 import sys
@@ -30,9 +30,10 @@ def residual(sim):
     return float(np.linalg.norm(r[live]) / np.linalg.norm(div[1:-1, 1:-1, 1:-1][live]))
 
 
-out = {"workload": name, "grid": [W, H, D], "acc": acc, "mg_cycles": cycles}
-for solver in ("jacobi", "mg"):
-    sim = F.Simulation(W, H, D, 1, acc=acc, solver=solver, quiet=1, dump_every=0, profile=1, mg_cycles=cycles)
+out = {"workload": name, "grid": [W, H, D], "acc": acc}
+runs = [("jacobi", 0)] + [("mg", c) for c in (([cycles] if len(sys.argv) > 2 else [2, 4, 8]))]
+for solver, cyc in runs:
+    sim = F.Simulation(W, H, D, 1, acc=acc, solver=solver, quiet=1, dump_every=0, profile=1, mg_cycles=max(cyc, 1))
     with tempfile.TemporaryDirectory() as tmp:
         add_obstacles(F, sim, cfg, tmp)
     for _ in range(3):
@@ -45,8 +46,14 @@ for solver in ("jacobi", "mg"):
     sim.sync()
     dt = (time.perf_counter() - t0) / 10
     fam = {k: round(sim.timing(k)[0] / 10, 4) for k in ("sweep", "sweep_pair", "sweep_triple", "multigrid", "divergence", "gradient", "advect")}
+    # one more projection of the developed flow, timed on its own, and the residual it leaves
+    sim.sync()
+    t0 = time.perf_counter()
     sim.project()
-    out[solver] = {"ms_per_step": round(dt * 1e3, 3), "kernel_ms_per_step": fam, "pressure_relative_residual": residual(sim),
-                   "mg_levels": sim._geti("mg_levels")}
+    sim.sync()
+    proj = (time.perf_counter() - t0) * 1e3
+    key = solver if solver == "jacobi" else "mg_%d_cycles" % cyc
+    out[key] = {"ms_per_step": round(dt * 1e3, 3), "kernel_ms_per_step": fam, "one_projection_ms": round(proj, 3),
+                "pressure_relative_residual": residual(sim), "mg_levels": sim._geti("mg_levels")}
     sim.close()
 print(json.dumps(out))
