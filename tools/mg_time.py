@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """solver=mg against solver=jacobi on the benchmark workloads, one box, one process: ms per step, ms per projection
 family, and the relative residual of the pressure equation each leaves (simulation.cpp:263-271's fixed point).
-python tools/mg_time.py [c2|c3] [cycles]   (no cycles argument: 2, 4 and 8)"""
+python tools/mg_time.py [c2|c3|c4] [cycles | 0 = 2, 4 and 8] [fp32|fp64]"""
 import json
 import os
 import sys
@@ -15,7 +15,8 @@ import fluid_simulation_amd as F  # noqa: E402
 from bench import WORKLOADS, add_obstacles  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c2"
-cycles = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+cycles = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else 0
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 cfg = WORKLOADS[name]
 W, H, D, acc = cfg["W"], cfg["H"], cfg["D"], cfg["acc"]
 
@@ -30,10 +31,10 @@ def residual(sim):
     return float(np.linalg.norm(r[live]) / np.linalg.norm(div[1:-1, 1:-1, 1:-1][live]))
 
 
-out = {"workload": name, "grid": [W, H, D], "acc": acc}
-runs = [("jacobi", 0)] + [("mg", c) for c in (([cycles] if len(sys.argv) > 2 else [2, 4, 8]))]
+out = {"workload": name, "grid": [W, H, D], "acc": acc, "precision": prec}
+runs = [("jacobi", 0)] + [("mg", c) for c in ([cycles] if cycles else [2, 4, 8])]
 for solver, cyc in runs:
-    sim = F.Simulation(W, H, D, 1, acc=acc, solver=solver, quiet=1, dump_every=0, profile=1, mg_cycles=max(cyc, 1))
+    sim = F.Simulation(W, H, D, 1, acc=acc, solver=solver, quiet=1, dump_every=0, profile=1, mg_cycles=max(cyc, 1), precision=prec)
     with tempfile.TemporaryDirectory() as tmp:
         add_obstacles(F, sim, cfg, tmp)
     for _ in range(3):
