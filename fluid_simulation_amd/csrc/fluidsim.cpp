@@ -200,7 +200,8 @@ struct Engine : EngineBase {
     T* gathered = nullptr;              // gathered advection source (z-slabs only), LEAD-shifted global array
     T* gathered3[3] = {nullptr, nullptr, nullptr};   // the same for the three sources of the fused velocity advection
     double* red = nullptr;              // stats scratch
-    T rb_omega = (T)1;                  // relaxation factor of the red-black passes of the running solve
+    T rb_omega = (T)1;                  // relaxation factor of the red-black / damped passes of the running solve
+    bool rb_damped = false;             // those passes are two damped Jacobi sweeps (solver=mg level 0) instead of one red-black iteration
     fs::Multigrid<T> mg;                // coarse levels of solver=mg; rebuilt when the flag bytes change
     bool mg_current = false;
     T* coltab = nullptr;                // clamp tables of the advection row kernels: 6 x (H+2)(D+2) (single GPU only)
@@ -380,7 +381,8 @@ struct Engine : EngineBase {
         else if (levels == 2 && !rb && pair_shape >= FUSED2)
             fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 2, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape - FUSED2, second);
         else if (levels == 2)
-            fs::launch_jacobi_pair<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape, second, omega);
+            fs::launch_jacobi_pair<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape, second, omega,
+                                      rb_damped);
         else
             fs::launch_jacobi<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, second);
     }
@@ -400,7 +402,7 @@ struct Engine : EngineBase {
 
     // Returns the id of the array holding the result (held); `cur` holds the initial
     // iterate (may equal rhs when the caller aliased a snapshot).
-    // smoother = true: the red-black form of the update with relaxation factor 1 (level-0 smoother of solver=mg)
+    // smoother = true: `sweeps` passes of two 6/7-damped Jacobi sweeps each (the level-0 smoothing step of solver=mg)
     int solve(int b, int cur, int rhs, T a, T c, int sweeps, int* result, bool smoother = false)
     {
         const T inv_c = (T)1 / c;                        // cRecip, :257
@@ -417,7 +419,8 @@ struct Engine : EngineBase {
         bool src_temp = false;
         // solver=rbsor: every iteration is one pass of the pair kernel (its two levels are the two colours)
         const bool rb = smoother || (S->solver == FS_SOLVER_RBSOR);
-        rb_omega = smoother ? (T)1 : (T)S->omega;
+        rb_omega = smoother ? (T)6 / (T)7 : (T)S->omega;
+        rb_damped = smoother;
         if (rb && !fs::pair_supported<T>(S->tune, g, sc))
             return fail(FS_EINVAL, "solver=rbsor / mg needs rows of at most 1024 cells and sweep_fuse >= 2");
         {
@@ -666,8 +669,9 @@ struct Engine : EngineBase {
     }
 
     // solver=mg (NOT the reference's arithmetic; defined in oracle/cpu_ref_mg.h): mg_cycles V-cycles on the pressure
-    // equation of :320.  Level 0 is smoothed by red-black passes of the reference's update (the pair kernel), the coarse
-    // levels live in multigrid.hip.  Single GPU.
+    // equation of :320.  Level 0 is smoothed by the reference's update as damped Jacobi sweeps, two per pass of the pair
+    // kernel (its red-black instantiation is 1.6x slower and smooths no better here), the coarse levels live in
+    // multigrid.hip.  Single GPU.
     int multigrid_levels() const override { return mg.levels(); }
     int multigrid_solve(int field, int prev, int* result)
     {

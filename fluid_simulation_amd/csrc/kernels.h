@@ -72,7 +72,8 @@ bool pair_supported(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc)
 template <class T>
 void launch_jacobi_pair(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
                         T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
-                        int second_first = -1, T omega = (T)0);   // omega != 0: one red-black SOR iteration instead
+                        int second_first = -1, T omega = (T)0, bool damped = false);
+// omega != 0: one red-black SOR iteration instead; with `damped`, two Jacobi sweeps damped by omega (q + omega*(r - q))
 // NL = `levels` (2 or 3) sweeps per pass, register-centred (sweep_fused.hip): fp32 x 3 for rows up to 512
 // cells, fp32 x 2 for rows of 513..1024 cells, fp64 x 2 for rows up to 512 cells.  On a z-slab `src` needs
 // `levels` current halo planes per side, `rhs` and `flags` levels-1.  plan = workgroup shape

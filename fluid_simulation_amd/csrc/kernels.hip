@@ -262,7 +262,9 @@ template void launch_jacobi<double>(hipStream_t, const SweepTune&, const GridDes
 // first and last level-1 row of a band have no level-2 output there (their level-1
 // neighbour row belongs to the next band); rows next to the walls use the ghost rows.
 // =====================================================================================
-template <class T, int NXW, int NYW, bool RB>
+// MODE: 0 = two Jacobi sweeps; 1 = one red-black iteration (solver=rbsor; coarse-level-style smoothing); 2 = two damped
+// Jacobi sweeps, q + omega*(r - q) in every cell (the level-0 smoother of solver=mg)
+template <class T, int NXW, int NYW, int MODE>
 __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                                      const T* __restrict__ rhs, T* __restrict__ dst,
                                                                      const uint8_t* __restrict__ flags, int b, T a,
@@ -368,6 +370,10 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] = (((par + e) & 1) == 0) ? old[e] + omega * (u[e] - old[e]) : old[e];
     };
+    auto damp4 = [&](T (&u)[4], const T (&old)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = old[e] + omega * (u[e] - old[e]);
+    };
     auto lds_row = [&](int z, int t, T (&out)[4]) {
         V4<T> q = *reinterpret_cast<const V4<T>*>(&tile[z & 3][t][x0 + 3]);
 #pragma unroll
@@ -401,7 +407,8 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
             lds_row(zo + 1, t, zp);
             T u[4], st[4];
             relax4(cc, left, right, ym, yp, zm, zp, X.rhs[r], u);
-            if (RB) blend4(u, cc, y, zo, 1);
+            if (MODE == 1) blend4(u, cc, y, zo, 1);
+            if (MODE == 2) damp4(u, cc);
             settle4(u, X.fl[r], st);
             const long base = row0 + (long)zo * g.sz + r * g.sy;
             V4<T> q;
@@ -465,7 +472,8 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
                     yp[e] = (r < RY - 1) ? A.core[r < RY - 1 ? r + 1 : r][e] : A.ht[e];
                 }
                 relax4(A.core[r], left, right, ym, yp, m[r], Bc[r], xc.rhs[r], u);
-                if (RB) blend4(u, A.core[r], y, zl, 0);
+                if (MODE == 1) blend4(u, A.core[r], y, zl, 0);
+                if (MODE == 2) damp4(u, A.core[r]);
                 settle4(u, xc.fl[r], st);
                 lds_put(zl, t, st);
                 if (x0 == 1) tile[zl & 3][t][3] = (b == 1) ? -u[0] : u[0];                      // ghost column x = 0
@@ -513,10 +521,12 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 template <class T, int NXW, int NYW>
 static void launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
                           const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt,
-                          int second_first, T omega)
+                          int second_first, T omega, bool damped)
 {
-    // omega == 0: two Jacobi sweeps; otherwise one red-black SOR iteration with that relaxation factor
-    auto kernel = (omega != (T)0) ? jacobi_pair_kernel<T, NXW, NYW, true> : jacobi_pair_kernel<T, NXW, NYW, false>;
+    // omega == 0: two Jacobi sweeps; otherwise one red-black SOR iteration with that relaxation factor, or (damped)
+    // two Jacobi sweeps damped by it
+    auto kernel = (omega == (T)0) ? jacobi_pair_kernel<T, NXW, NYW, 0>
+                                  : damped ? jacobi_pair_kernel<T, NXW, NYW, 2> : jacobi_pair_kernel<T, NXW, NYW, 1>;
     constexpr int BY = NYW * 2;
     const int planes = z_last - z_first + 1;
     if (planes <= 0) return;
@@ -577,7 +587,7 @@ int pair_shape_count<double>(const GridDesc&) { return 1; }
 template <>
 void launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const float* src,
                                const float* rhs, float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first,
-                               int z_last, int shape, int second_first, float omega)
+                               int z_last, int shape, int second_first, float omega, bool damped)
 {
     // shape: 0 = 12 waves (768 threads, <=168 VGPRs), 2 = 10 waves, 1 = 8 waves, 3 = 16 waves (spills;
     // tuning tool only).  All shapes give identical results; the host driver times 0..count-1 once per
@@ -587,7 +597,7 @@ void launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const Grid
     const int alt = shape >> 3;                          // which of the three best chunk counts
     shape &= 7;
     if (tune.pair_shape > 0) shape = tune.pair_shape;
-#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega)
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 2) FS_PAIR(1, 10); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 2) FS_PAIR(2, 5); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
@@ -597,14 +607,14 @@ void launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const Grid
 template <>
 void launch_jacobi_pair<double>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const double* src,
                                 const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
-                                int z_first, int z_last, int shape, int second_first, double omega)
+                                int z_first, int z_last, int shape, int second_first, double omega, bool damped)
 {
     const int alt = shape < 0 ? 0 : (shape >> 3);
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
-    if (nxw == 1) launch_pair_v<double, 1, 8>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
-    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
-    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
-    else launch_pair_v<double, 4, 2>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega);
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped);
+    else launch_pair_v<double, 4, 2>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped);
 }
 
 // =====================================================================================

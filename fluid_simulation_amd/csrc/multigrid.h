@@ -22,12 +22,14 @@ struct MgLevel {
     T *wx, *wy, *wz;   // weight of the face on the minus side of a cell (wx[c] couples c-1 and c; x = 1..W+1)
     T *d, *dg;         // Dirichlet term (links to solid cells); diagonal (0 = dead cell: no links at all)
     T *e, *b;          // unknown (correction), right-hand side
+    uint8_t* reg;      // 1 = regular cell: all six weights 1, d = 0 (diagonal 6): the kernels then skip the coefficient arrays
 };
 
 template <class T>
 struct Multigrid {
     std::vector<MgLevel<T>> lv;      // lv[0] is unused (level 0 is the simulation grid); lv[1..] the coarse levels
     T* pool = nullptr;               // one allocation behind all level arrays
+    uint8_t* reg_pool = nullptr;     // ... and one behind the regular-cell bytes
     int W0 = 0, H0 = 0, D0 = 0;
 
     int levels() const { return (int)lv.size(); }          // including level 0

@@ -80,7 +80,18 @@ __global__ __launch_bounds__(256) void mg_diag_kernel(MgLevel<T> c)
     const int X = 1 + blockIdx.x * 64 + threadIdx.x, Y = 1 + blockIdx.y * 4 + threadIdx.y, Z = 1 + blockIdx.z;
     if (X > c.W || Y > c.H) return;
     const long C = lat(c, X, Y, Z);
-    c.dg[C] = (((((c.wx[C] + c.wx[C + 1]) + c.wy[C]) + c.wy[C + c.sy]) + c.wz[C]) + c.wz[C + c.sz]) + c.d[C];
+    const T one = (T)1;
+    const T xm = c.wx[C], xp = c.wx[C + 1], ym = c.wy[C], yp = c.wy[C + c.sy], zm = c.wz[C], zp = c.wz[C + c.sz], d = c.d[C];
+    c.dg[C] = (((((xm + xp) + ym) + yp) + zm) + zp) + d;
+    // regular: the general expressions reduce to the plain 7-point ones bit for bit (1 * e = e, diagonal exactly 6)
+    c.reg[C] = (xm == one && xp == one && ym == one && yp == one && zm == one && zp == one && d == (T)0) ? 1 : 0;
+}
+
+template <class T>
+__device__ __forceinline__ T plain_neighbours(const MgLevel<T>& l, long c)
+{
+    const T* e = l.e;
+    return ((((e[c - 1] + e[c + 1]) + e[c - l.sy]) + e[c + l.sy]) + e[c - l.sz]) + e[c + l.sz];
 }
 
 template <class T>
@@ -99,6 +110,10 @@ __global__ __launch_bounds__(256) void mg_smooth_kernel(MgLevel<T> l, int colour
     const int x = 1 + 2 * (blockIdx.x * 64 + threadIdx.x) + (((y + z + colour) & 1) ? 0 : 1);
     if (x > l.W || y > l.H) return;
     const long c = lat(l, x, y, z);
+    if (l.reg[c]) {
+        l.e[c] = (l.b[c] + plain_neighbours(l, c)) / (T)6;
+        return;
+    }
     const T dg = l.dg[c];
     if (!(dg > (T)0)) return;
     l.e[c] = (l.b[c] + weighted_neighbours(l, c)) / dg;
@@ -107,6 +122,7 @@ __global__ __launch_bounds__(256) void mg_smooth_kernel(MgLevel<T> l, int colour
 template <class T>
 __device__ __forceinline__ T residual_at(const MgLevel<T>& l, long c)
 {
+    if (l.reg[c]) return (l.b[c] + plain_neighbours(l, c)) - (T)6 * l.e[c];
     const T dg = l.dg[c];
     if (!(dg > (T)0)) return (T)0;
     return (l.b[c] + weighted_neighbours(l, c)) - dg * l.e[c];
@@ -142,38 +158,67 @@ __device__ __forceinline__ T residual0_at(const GridDesc& g, const uint8_t* flag
     return (rhs[c] + nb) - (T)6 * p[c];
 }
 
-// One thread per FINE cell column pair: a lane computes the residuals of its x at the four (y, z) children of coarse
-// row (Y, Z) -- every load is a coalesced row segment -- and the even lane (x odd: the first child) adds its odd
-// neighbour's by wave shuffle, in the order the oracle sums the eight children.
+// A lane owns four x-consecutive fine cells of the two rows and two planes below coarse row (Y, Z): 16 residuals from
+// twelve 16-byte row loads of p (plus the columns beside them), four of rhs and four flag words, all in flight at once;
+// they make two coarse cells, summed in the oracle's order (x fastest, then y, then z).
 template <class T>
 __global__ __launch_bounds__(256) void mg_restrict0_kernel(GridDesc g, const uint8_t* __restrict__ flags, const T* __restrict__ p,
                                                             const T* __restrict__ rhs, MgLevel<T> c)
 {
-    const int x = 1 + blockIdx.x * 64 + threadIdx.x;
+    const int x0 = 1 + 4 * (blockIdx.x * 64 + threadIdx.x);
     const int Y = 1 + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y), Z = 1 + blockIdx.z;
-    if (Y > c.H) return;                                  // wave-uniform
-    const int y = 2 * Y - 1, z = 2 * Z - 1;
-    const bool on = x <= g.W;
-    T r00 = (T)0, r10 = (T)0, r01 = (T)0, r11 = (T)0;     // (dy, dz)
-    if (on) {
-        r00 = residual0_at(g, flags, p, rhs, x, y, z);
-        r10 = residual0_at(g, flags, p, rhs, x, y + 1, z);
-        r01 = residual0_at(g, flags, p, rhs, x, y, z + 1);
-        r11 = residual0_at(g, flags, p, rhs, x, y + 1, z + 1);
+    if (x0 > g.W || Y > c.H) return;
+    const int y0 = 2 * Y - 1, z0 = 2 * Z - 1;
+    const long i00 = cell(g, x0, y0, z0);
+    auto ld = [&](long i) { return *reinterpret_cast<const V4<T>*>(p + i); };
+    // centre rows [dz][dy], the rows beside them in y ([dz][0] = y0-1, [dz][1] = y0+2) and in z ([0][dy] = z0-1, [1][dy] = z0+2)
+    V4<T> cen[2][2], ynb[2][2], znb[2][2], rh[2][2];
+    T xl[2][2], xr[2][2];
+    unsigned fw[2][2];
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const long i = i00 + dy * g.sy + dz * g.sz;
+            cen[dz][dy] = ld(i);
+            rh[dz][dy] = *reinterpret_cast<const V4<T>*>(rhs + i);
+            fw[dz][dy] = *reinterpret_cast<const unsigned*>(flags + i);
+            xl[dz][dy] = p[i - 1];
+            xr[dz][dy] = p[i + 4];
+            znb[dz][dy] = ld(i00 + dy * g.sy + (dz ? 2 : -1) * g.sz);
+        }
+        ynb[dz][0] = ld(i00 - g.sy + dz * g.sz);
+        ynb[dz][1] = ld(i00 + 2 * g.sy + dz * g.sz);
     }
-    const T n00 = __shfl_down(r00, 1), n10 = __shfl_down(r10, 1), n01 = __shfl_down(r01, 1), n11 = __shfl_down(r11, 1);
-    if (!on || (threadIdx.x & 1)) return;
-    T r = r00;
-    r = r + n00;
-    r = r + r10;
-    r = r + n10;
-    r = r + r01;
-    r = r + n01;
-    r = r + r11;
-    r = r + n11;
-    const long C = lat(c, (x + 1) >> 1, Y, Z);
-    c.b[C] = (c.dg[C] > (T)0) ? (T)0.5 * r : (T)0;
-    c.e[C] = (T)0;
+    T sum[2] = {(T)0, (T)0};                              // coarse cells X, X+1
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const V4<T>& v = cen[dz][dy];
+                const T xp = (e < 3) ? v.e[e < 3 ? e + 1 : 3] : xr[dz][dy];
+                const T xm = (e > 0) ? v.e[e > 0 ? e - 1 : 0] : xl[dz][dy];
+                const T yp = dy ? ynb[dz][1].e[e] : cen[dz][1].e[e];
+                const T ym = dy ? cen[dz][0].e[e] : ynb[dz][0].e[e];
+                const T zp = dz ? znb[1][dy].e[e] : cen[1][dy].e[e];
+                const T zm = dz ? cen[0][dy].e[e] : znb[0][dy].e[e];
+                const T nb = xp + xm + yp + ym + zp + zm;     // order of simulation.cpp:264-268
+                const bool solid = ((fw[dz][dy] >> (8 * e)) & F_SOLID) != 0;
+                const T r = (solid || x0 + e > g.W) ? (T)0 : (rh[dz][dy].e[e] + nb) - (T)6 * v.e[e];
+                // the oracle's running sum visits the children in exactly this loop order (dz outer, dy, then x)
+                if (dz == 0 && dy == 0 && (e & 1) == 0) sum[e >> 1] = r;
+                else sum[e >> 1] = sum[e >> 1] + r;
+            }
+    const int X = (x0 + 1) >> 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (X + k > c.W) continue;
+        const long C = lat(c, X + k, Y, Z);
+        c.b[C] = (c.dg[C] > (T)0) ? (T)0.5 * sum[k] : (T)0;
+        c.e[C] = (T)0;
+    }
 }
 
 // trilinear interpolation of level c's correction at fine cell (x, y, z); neighbour index clamped at the walls
@@ -205,66 +250,76 @@ __global__ __launch_bounds__(256) void mg_prolong_kernel(MgLevel<T> c, MgLevel<T
 }
 
 // level 0: p += correction at the cells that are not solid, then setBounds(0, p) (solids already hold 0).
-// Four x-consecutive cells per lane (one 16-byte load / store of p, one flag word): they share the coarse columns
-// X-1 .. X+2 of four coarse rows.
+// A lane owns four x-consecutive cells of the two rows and two planes below coarse row (Y, Z) (16-byte accesses, four
+// rows in flight); the 16 cells share the coarse columns X-1 .. X+2 of the 3 x 3 coarse rows around (Y, Z).
 template <class T>
 __global__ __launch_bounds__(256) void mg_prolong0_kernel(MgLevel<T> c, GridDesc g, SlabCtx sc, const uint8_t* __restrict__ flags,
                                                            T* __restrict__ p)
 {
     const int x0 = 1 + 4 * (blockIdx.x * 64 + threadIdx.x);
-    const int y = 1 + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y), z = 1 + blockIdx.z;
-    if (x0 > g.W || y > g.H) return;
-    const long i = cell(g, x0, y, z);
-    const int X = (x0 + 1) >> 1, Y = (y + 1) >> 1, Z = (z + 1) >> 1;
-    const int Yn = min(max((y & 1) ? Y - 1 : Y + 1, 1), c.H), Zn = min(max((z & 1) ? Z - 1 : Z + 1, 1), c.D);
+    const int Y = 1 + blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.y), Z = 1 + blockIdx.z;
+    if (x0 > g.W || Y > c.H) return;
+    const int X = (x0 + 1) >> 1;
     // coarse columns of the four cells: own (X, X, X+1, X+1), neighbour (X-1, X+1, X, X+2), clamped at the walls
-    const int Xm = max(X - 1, 1), X1 = min(X + 1, c.W), X2 = min(X + 2, c.W);
-    const T a = (T)0.75, q = (T)0.25;
-    T row[4][4];                                          // [(Y,Z), (Yn,Z), (Y,Zn), (Yn,Zn)][column Xm, X, X1, X2]
-    {
-        const long rows[4] = { lat(c, 0, Y, Z), lat(c, 0, Yn, Z), lat(c, 0, Y, Zn), lat(c, 0, Yn, Zn) };
+    const int col[4] = { max(X - 1, 1), X, min(X + 1, c.W), min(X + 2, c.W) };
+    const int Yc[3] = { max(Y - 1, 1), Y, min(Y + 1, c.H) }, Zc[3] = { max(Z - 1, 1), Z, min(Z + 1, c.D) };
+    T R[3][3][4];                                         // [z][y][column]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            row[k][0] = c.e[rows[k] + Xm];
-            row[k][1] = c.e[rows[k] + X];
-            row[k][2] = c.e[rows[k] + X1];
-            row[k][3] = c.e[rows[k] + X2];
+    for (int zi = 0; zi < 3; ++zi)
+#pragma unroll
+        for (int yi = 0; yi < 3; ++yi) {
+            const long row = lat(c, 0, Yc[yi], Zc[zi]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) R[zi][yi][k] = c.e[row + col[k]];
         }
-    }
-    V4<T> v = *reinterpret_cast<const V4<T>*>(p + i);
-    const unsigned fw = *reinterpret_cast<const unsigned*>(flags + i);
-    T u[4];
+    const T a = (T)0.75, q = (T)0.25;
+    const long i00 = cell(g, x0, 2 * Y - 1, 2 * Z - 1);
+    V4<T> v[2][2];
+    unsigned fw[2][2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int own = 1 + (e >> 1);                     // column index in row[][]: cells 0, 1 -> X; cells 2, 3 -> X+1
-        // the neighbour column of an odd x (cells 0, 2) is the one below, of an even x the one above; the clamp of the
-        // oracle's index (X-1 -> 1, X+1 -> W) is already in Xm / X1 / X2
-        const int nbr = (e & 1) ? own + 1 : own - 1;
-        const T x00 = a * row[0][own] + q * row[0][nbr];
-        const T x10 = a * row[1][own] + q * row[1][nbr];
-        const T x01 = a * row[2][own] + q * row[2][nbr];
-        const T x11 = a * row[3][own] + q * row[3][nbr];
-        const T y0 = a * x00 + q * x10;
-        const T y1 = a * x01 + q * x11;
-        const T corr = a * y0 + q * y1;
-        const bool solid = ((fw >> (8 * e)) & F_SOLID) != 0;
-        u[e] = (x0 + e <= g.W) ? (solid ? v.e[e] : v.e[e] + corr) : (T)0;
-    }
-    // setBounds(0, p): ghost faces mirror the (un-zeroed) interior values; ghost edges and row padding stay 0
-    V4<T> o, face;
+    for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int x = x0 + e;
-        o.e[e] = (x <= g.W) ? u[e] : ((x == g.W + 1) ? u[e - (e > 0 ? 1 : 0)] : (T)0);
-        face.e[e] = (x <= g.W) ? u[e] : (T)0;
-    }
-    *reinterpret_cast<V4<T>*>(p + i) = o;
-    if (x0 == 1) p[i - 1] = u[0];
-    if (x0 + 3 == g.W) p[i + 4] = u[3];                   // the ghost x = W+1 when W is a multiple of 4
-    if (y == 1) *reinterpret_cast<V4<T>*>(p + i - g.sy) = face;
-    if (y == g.H) *reinterpret_cast<V4<T>*>(p + i + g.sy) = face;
-    if (z == 1 && sc.lo_wall) *reinterpret_cast<V4<T>*>(p + i - g.sz) = face;
-    if (z == g.D && sc.hi_wall) *reinterpret_cast<V4<T>*>(p + i + g.sz) = face;
+        for (int dy = 0; dy < 2; ++dy) {
+            v[dz][dy] = *reinterpret_cast<const V4<T>*>(p + i00 + dy * g.sy + dz * g.sz);
+            fw[dz][dy] = *reinterpret_cast<const unsigned*>(flags + i00 + dy * g.sy + dz * g.sz);
+        }
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int y = 2 * Y - 1 + dy, z = 2 * Z - 1 + dz;
+            const long i = i00 + dy * g.sy + dz * g.sz;
+            const int yn = dy ? 2 : 0, zn = dz ? 2 : 0;      // the neighbour row of an odd y (dy = 0) is the one below, ...
+            T u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int own = 1 + (e >> 1), nbr = (e & 1) ? own + 1 : own - 1;
+                const T x00 = a * R[1][1][own] + q * R[1][1][nbr];
+                const T x10 = a * R[1][yn][own] + q * R[1][yn][nbr];
+                const T x01 = a * R[zn][1][own] + q * R[zn][1][nbr];
+                const T x11 = a * R[zn][yn][own] + q * R[zn][yn][nbr];
+                const T y0 = a * x00 + q * x10;
+                const T y1 = a * x01 + q * x11;
+                const T corr = a * y0 + q * y1;
+                const bool solid = ((fw[dz][dy] >> (8 * e)) & F_SOLID) != 0;
+                u[e] = (x0 + e <= g.W) ? (solid ? v[dz][dy].e[e] : v[dz][dy].e[e] + corr) : (T)0;
+            }
+            // setBounds(0, p): ghost faces mirror the (un-zeroed) interior values; ghost edges and row padding stay 0
+            V4<T> o, face;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int x = x0 + e;
+                o.e[e] = (x <= g.W) ? u[e] : ((x == g.W + 1) ? u[e > 0 ? e - 1 : 0] : (T)0);
+                face.e[e] = (x <= g.W) ? u[e] : (T)0;
+            }
+            *reinterpret_cast<V4<T>*>(p + i) = o;
+            if (x0 == 1) p[i - 1] = u[0];
+            if (x0 + 3 == g.W) p[i + 4] = u[3];           // the ghost x = W+1 when W is a multiple of 4
+            if (y == 1) *reinterpret_cast<V4<T>*>(p + i - g.sy) = face;
+            if (y == g.H) *reinterpret_cast<V4<T>*>(p + i + g.sy) = face;
+            if (z == 1 && sc.lo_wall) *reinterpret_cast<V4<T>*>(p + i - g.sz) = face;
+            if (z == g.D && sc.hi_wall) *reinterpret_cast<V4<T>*>(p + i + g.sz) = face;
+        }
 }
 
 // The small levels (at most BOTTOM_CELLS cells each) as ONE launch of one workgroup: their launches would cost more than
@@ -346,7 +401,9 @@ template <class T>
 void Multigrid<T>::release()
 {
     if (pool) hipFree(pool);
+    if (reg_pool) hipFree(reg_pool);
     pool = nullptr;
+    reg_pool = nullptr;
     lv.clear();
     W0 = H0 = D0 = 0;
 }
@@ -357,7 +414,7 @@ hipError_t Multigrid<T>::build(hipStream_t st, const GridDesc& g, const uint8_t*
     if (g.W != W0 || g.H != H0 || g.D != D0 || lv.empty()) {
         release();
         W0 = g.W; H0 = g.H; D0 = g.D;
-        lv.push_back(MgLevel<T>{g.W, g.H, g.D, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+        lv.push_back(MgLevel<T>{g.W, g.H, g.D, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
         int W = g.W, H = g.H, D = g.D;
         size_t total = 0;
         while (W % 2 == 0 && H % 2 == 0 && D % 2 == 0 && W / 2 >= MG_MIN_DIM && H / 2 >= MG_MIN_DIM && D / 2 >= MG_MIN_DIM) {
@@ -372,12 +429,16 @@ hipError_t Multigrid<T>::build(hipStream_t st, const GridDesc& g, const uint8_t*
         }
         if (total) {
             hipError_t e = hipMalloc((void**)&pool, total * sizeof(T));
-            if (e != hipSuccess) { lv.clear(); W0 = 0; return e; }
+            if (e == hipSuccess) e = hipMalloc((void**)&reg_pool, total / 7);
+            if (e != hipSuccess) { release(); return e; }
             T* q = pool;
+            uint8_t* rq = reg_pool;
             for (size_t i = 1; i < lv.size(); ++i) {
                 MgLevel<T>& l = lv[i];
                 T** arrs[] = { &l.wx, &l.wy, &l.wz, &l.d, &l.dg, &l.e, &l.b };
                 for (T** a : arrs) { *a = q; q += l.n; }
+                l.reg = rq;
+                rq += l.n;
             }
         }
     }
@@ -385,6 +446,7 @@ hipError_t Multigrid<T>::build(hipStream_t st, const GridDesc& g, const uint8_t*
         size_t total = 0;
         for (size_t i = 1; i < lv.size(); ++i) total += 7 * (size_t)lv[i].n;
         hipError_t e = hipMemsetAsync(pool, 0, total * sizeof(T), st);     // ghosts, dead cells and wall faces stay 0
+        if (e == hipSuccess) e = hipMemsetAsync(reg_pool, 0, total / 7, st);
         if (e != hipSuccess) return e;
     }
     for (size_t i = 1; i < lv.size(); ++i) {
@@ -409,7 +471,7 @@ void Multigrid<T>::coarse_correction(hipStream_t st, const GridDesc& g, const Sl
             for (int colour = 0; colour < 2; ++colour)
                 hipLaunchKernelGGL((mg_smooth_kernel<T>), grd((l.W + 1) / 2, l.H, l.D), blk(), 0, st, l, colour);
     };
-    hipLaunchKernelGGL((mg_restrict0_kernel<T>), grd(g.W, lv[1].H, lv[1].D), blk(), 0, st, g, flags, p, rhs, lv[1]);
+    hipLaunchKernelGGL((mg_restrict0_kernel<T>), grd((g.W + 3) / 4, lv[1].H, lv[1].D), blk(), 0, st, g, flags, p, rhs, lv[1]);
     int lb = nl;                                          // first level of the single-workgroup bottom
     for (int l = 1; l < nl; ++l)
         if ((long)lv[l].W * lv[l].H * lv[l].D <= BOTTOM_CELLS && nl - l <= BOTTOM_MAX) { lb = l; break; }
@@ -431,7 +493,7 @@ void Multigrid<T>::coarse_correction(hipStream_t st, const GridDesc& g, const Sl
         hipLaunchKernelGGL((mg_prolong_kernel<T>), grd(lv[l].W, lv[l].H, lv[l].D), blk(), 0, st, lv[l + 1], lv[l]);
         smooth(lv[l], post);
     }
-    hipLaunchKernelGGL((mg_prolong0_kernel<T>), grd((g.W + 3) / 4, g.H, g.D), blk(), 0, st, lv[1], g, sc, flags, p);
+    hipLaunchKernelGGL((mg_prolong0_kernel<T>), grd((g.W + 3) / 4, lv[1].H, lv[1].D), blk(), 0, st, lv[1], g, sc, flags, p);
 }
 
 template struct Multigrid<float>;

@@ -106,7 +106,7 @@ int fs_destroy(fs_sim* s);
  *                 two-sweep kernels (jacobi_pair_kernel / jacobi_fused_kernel<NL=2>) runs those passes;
  *   "advect_kernels" "cell" (default: one thread per cell) | "celltab" (the same reading clamped traces from the
  *                 column tables) | "row" (four cells per lane, clamp tables); all bit-identical, none faster by > 5 %;
- *   "mg_cycles" (default 4: about the time of the 80 sweeps of config 3, residual 24x smaller), "mg_pre", "mg_post" (smoothing steps before / after the coarse correction, default 1),
+ *   "mg_cycles" (default 4: 75 % of the time of the 80 sweeps of config 3, residual 34x smaller), "mg_pre", "mg_post" (smoothing steps before / after the coarse correction, default 1),
  *                 "mg_coarse_iters" (iterations on the coarsest level, default 30): solver "mg" only;
  *   "wall_free"   "auto" (default) | "0" | "1": whether workgroups of the three-sweep kernel that touch no wall run its
  *                 wall-free second body (auto: when a launch has more than 256 workgroups);

@@ -12,8 +12,8 @@
  *   fluid cell c:  6 p_c - sum of its six neighbours = div_c,  where a solid neighbour counts 0
  *   (setBounds zeroes solids, :219-223) and a wall ghost mirrors p_c (:187-215).
  * V-cycles on cell-centred 2x2x2 coarsening.  Level 0 is the simulation grid and keeps the
- * reference's arithmetic (red-black ordering of the update of :263-269, then setBounds).  Coarser
- * levels carry per-face weights w and a Dirichlet term d:
+ * reference's arithmetic (the update of :263-269 as damped Jacobi sweeps, then setBounds; mg_smooth0).
+ * Coarser levels (red-black Gauss-Seidel) carry per-face weights w and a Dirichlet term d:
  *   (sum_f w_f + d_C) e_C - sum_f w_f e_nbr(f) = b_C
  * with  w(coarse face) = 1/4 * sum of the four fine face weights it covers  (fine level 0: 1 where
  * both cells are fluid, else 0; wall faces 0) and  d_C = 1/2 * sum of its children's d  (level 0:
@@ -168,7 +168,32 @@ static real mg_interp(const mg_level* c, int x, int y, int z)
     return a * y0 + q * y1;
 }
 
-static void rb_iterations(cr_sim* s, int b, real* q, const real* rhs, real a, real inv_c, real om, int n);
+/* Level-0 smoothing step: two Jacobi sweeps of the reference's update (simulation.cpp:263-269, from the previous
+ * iterate), each damped -- q + (6/7)(r - q) in every interior cell -- and followed by setBounds.  (6/7 is the damping
+ * that makes Jacobi a smoother for the 7-point operator; undamped it leaves the checkerboard mode alone.) */
+static void mg_smooth0(cr_sim* s, real* q, const real* rhs, int steps)
+{
+    const int W = s->W, H = s->H, D = s->D;
+    const size_t sy = s->sy, sz = s->sz;
+    const real inv_c = (real)1 / (real)6, om = (real)6 / (real)7;
+    real* nxt = s->scratch;
+    for (int it = 0; it < 2 * steps; ++it) {
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int z = 1; z <= D; ++z)
+            for (int y = 1; y <= H; ++y)
+                for (int x = 1; x <= W; ++x) {
+                    size_t c = AT(s, x, y, z);
+                    real nb = q[c + 1] + q[c - 1] + q[c + sy] + q[c - sy] + q[c + sz] + q[c - sz];
+                    real r = (rhs[c] + (real)1 * nb) * inv_c;
+                    nxt[c] = q[c] + om * (r - q[c]);
+                }
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int z = 1; z <= D; ++z)
+            for (int y = 1; y <= H; ++y)
+                memcpy(&q[AT(s, 1, y, z)], &nxt[AT(s, 1, y, z)], (size_t)W * sizeof(real));
+        enforce_bounds(s, 0, q);
+    }
+}
 
 typedef struct mg_ctx {
     cr_sim* s;
@@ -237,14 +262,13 @@ static int mg_solve(cr_sim* s, real* p, const real* rhs)
             mg_coarsen(s, l == 1 ? NULL : &m.lv[l - 1], &m.lv[l]);
         }
     }
-    const real inv_c = (real)1 / (real)6;
     for (int cyc = 0; cyc < s->mg_cycles; ++cyc) {
         if (m.nl == 1) {
-            rb_iterations(s, 0, p, rhs, (real)1, inv_c, (real)1, s->mg_coarse);
+            mg_smooth0(s, p, rhs, s->mg_coarse);
             continue;
         }
         mg_level* C = &m.lv[1];
-        rb_iterations(s, 0, p, rhs, (real)1, inv_c, (real)1, s->mg_pre);
+        mg_smooth0(s, p, rhs, s->mg_pre);
 #pragma omp parallel for collapse(2) schedule(static)
         for (int Z = 1; Z <= C->D; ++Z)
             for (int Y = 1; Y <= C->H; ++Y)
@@ -271,7 +295,7 @@ static int mg_solve(cr_sim* s, real* p, const real* rhs)
                     if (s->f[CR_OBS][c] != (real)1) p[c] = p[c] + mg_interp(C, x, y, z);
                 }
         enforce_bounds(s, 0, p);
-        rb_iterations(s, 0, p, rhs, (real)1, inv_c, (real)1, s->mg_post);
+        mg_smooth0(s, p, rhs, s->mg_post);
     }
     for (int l = 1; l < m.nl; ++l) mg_free_level(&m.lv[l]);
     free(m.lv);

@@ -49,25 +49,27 @@ def test_multigrid_mode_solves_the_pressure_equation(oracle_mod, shape, fp64):
 
 
 def test_multigrid_mode_without_coarse_levels_and_outside_the_projection(oracle_mod):
-    """A grid whose extents cannot be halved gets no coarse levels (the cycles are red-black iterations on the grid
-    itself); diffusion under CR_MG is the Jacobi path."""
+    """A grid whose extents cannot be halved gets no coarse levels (the cycles are damped Jacobi sweeps on the grid
+    itself and still reduce the residual); diffusion under CR_MG is the Jacobi path."""
     O = oracle_mod
     W, H, D = 15, 9, 7
     mask = ball_mask(W, H, D, 5, 4, 3, 2.0)
     a = O.Oracle(W, H, D, solver=O.MG, threads=4, acc=6, mg=(2, 1, 1, 3))
-    b = O.Oracle(W, H, D, solver=O.RBSOR, omega=1.0, threads=4, acc=6)
+    a4 = O.Oracle(W, H, D, solver=O.MG, threads=4, acc=6, mg=(8, 1, 1, 3))
     j = O.Oracle(W, H, D, solver=O.JACOBI, threads=4, acc=6)
     rng = np.random.default_rng(5)
     v = rng.standard_normal((D + 2, H + 2, W + 2)).astype(np.float32)
-    for o in (a, b, j):
+    for o in (a, a4, j):
         o.set_mask(mask)
         for f in (O.VX, O.VY, O.VZ):
             o.set(f, v)
     a.project()
-    b.project()                                                            # 6 red-black iterations = 2 cycles x 3
-    assert a.get(O.P).tobytes() == b.get(O.P).tobytes()
-    a.diffuse(1, O.VX, O.VX0)
-    j.set(O.VX, a.get(O.VX))                                               # (diffuse wrote it; restart both from one state)
+    a4.project()
+    r2 = relative_residual(a.get(O.P), a.get(O.DIV), mask)
+    r8 = relative_residual(a4.get(O.P), a4.get(O.DIV), mask)
+    assert r8 < r2 < 1.0, (r2, r8)
+    a.set(O.VX, v)
+    j.set(O.VX, v)
     a.set(O.VX0, v)
     j.set(O.VX0, v)
     a.diffuse(1, O.VX, O.VX0)
