@@ -88,6 +88,16 @@ int main(int argc, char** argv)
         CHECK(fs_set_option(s, "advect_kernels", "row"));
         CHECK(fs_run_one(s));
         CHECK(fs_set_option(s, "advect_kernels", "cell"));
+        CHECK(fs_set_option(s, "solver", "mg"));                // multigrid pressure solve: 40x24x20 halves twice
+        CHECK(fs_set_option(s, "mg_cycles", "2"));
+        CHECK(fs_run_one(s));
+        CHECK(fs_add_obstacle(s, 7, 7, 7));                      // rebuilds the coarse operators
+        CHECK(fs_run_one(s));
+        CHECK(fs_linear_solver(s, 0, FS_PRESSURE, FS_DIVERGENCE, 1.0f, 6.0f));
+        int mgl = 0;
+        CHECK(fs_get_int(s, "mg_levels", &mgl));
+        if (mgl != 3) return 9;
+        if (fs_set_option(s, "mg_pre", "0") != FS_EINVAL) return 10;
         CHECK(fs_set_option(s, "solver", "gs_lex"));
         CHECK(fs_run_one(s));
         CHECK(fs_destroy(s));
