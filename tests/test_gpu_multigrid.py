@@ -125,3 +125,30 @@ def test_linear_solver_with_the_pressure_coefficients_runs_v_cycles(F, oracle_mo
     sim.linear_solver(1, F.VX, F.VY_PREV, 0.3, 2.8)
     ora.linear_solver(1, O.VX, O.VY0, 0.3, 2.8)
     assert bits_equal(sim.get(F.VX), ora.get(O.VX))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_multigrid_on_random_grids_and_random_solids(F, oracle_mod, seed):
+    """Seeded random even grids with scattered solids (2-40 % of the cells: isolated fluid pockets, coarse cells that are
+    entirely solid, fluid cells whose every neighbour is solid) and random cycle parameters, two steps, against the
+    oracle bit for bit."""
+    O = oracle_mod
+    rng = np.random.default_rng(seed)
+    W, H, D = (int(2 * rng.integers(4, 40)), int(2 * rng.integers(4, 24)), int(2 * rng.integers(4, 20)))
+    if seed % 2 == 0:
+        W, H, D = 8 * (W // 8 + 1), 8 * (H // 8 + 1), 8 * (D // 8 + 1)          # at least three levels
+    fp64 = bool(seed % 3 == 0)
+    mg = (int(rng.integers(1, 4)), int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 12)))
+    m = np.zeros((D + 2, H + 2, W + 2), bool)
+    m[1:-1, 1:-1, 1:-1] = rng.random((D, H, W)) < rng.choice([0.02, 0.1, 0.4])
+    kw = dict(precision="fp64") if fp64 else {}
+    sim = F.Simulation(W, H, D, 1, acc=3, solver="mg", quiet=1, mg_cycles=mg[0], mg_pre=mg[1], mg_post=mg[2],
+                       mg_coarse_iters=mg[3], **kw)
+    ora = O.Oracle(W, H, D, solver=O.MG, fp64=fp64, threads=8, acc=3, mg=mg)
+    sim.set_mask(m)
+    ora.set_mask(m)
+    for _ in range(2):
+        sim.run_one()
+        ora.run_one()
+    for f in range(11):
+        assert bits_equal(sim.get(f), ora.get(f)), "%s %s seed %d: %s" % ((W, H, D), mg, seed, F.FIELD_NAMES[f])
