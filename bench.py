@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0,
                     help="seconds for the one-thread leg of cpu_baseline; below 5 the 256^3 sample is skipped (tests)")
+    ap.add_argument("--launch-plans", default=None,
+                    help="\"<two-sweep plan id>,<three-sweep plan id>\": replay the launch plans of another run instead of timing "
+                         "them (tools/make_profiles.sh: counter passes must run what the bench line ran)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "shm"],
                     help="shm: development rehearsal of the N>1 path on fewer GPUs than ranks (host-staged "
                          "halo planes through shared memory, torch.distributed over gloo); never a result")
@@ -253,6 +256,8 @@ def main():
         slab_parity = slab_parity_check(F, fsdist, dist, rank, world, args.transport, ctl_device)
 
     sim = F.Simulation(W, H, D, args.steps, acc=acc, precision=args.precision, quiet=1, dump_every=0, profile=1)
+    if args.launch_plans:
+        sim.set_option("launch_plans", args.launch_plans)
     if world > 1:
         uid = fsdist.share_unique_id(dist, lambda: F.comm_unique_id(args.transport), rank, device=ctl_device)
         sim.comm_init(rank, world, uid)

@@ -96,6 +96,7 @@ struct fs_sim {
     bool fp64 = false;
     int solver = FS_SOLVER_JACOBI;
     float omega = 1.0f;          // relaxation factor of solver=rbsor
+    int plan_two = -2, plan_three = -2;   // "launch_plans": replay these instead of timing (-2: not set)
     int mg_cycles = 4, mg_pre = 1, mg_post = 1, mg_coarse = 30;   // solver=mg: V-cycles per pressure solve, smoothing steps, coarsest-level iterations
     std::string dump_dir = "data";
     int dump_every = 1;
@@ -570,6 +571,15 @@ struct Engine : EngineBase {
         };
         float best = 1e30f;
         int best_cand = -1;
+        // "launch_plans" = "<two-sweep id>,<three-sweep id>" (as fs_get_int "pair_shape" / "triple_plan" report them): replay
+        // the plans of another run instead of timing (tools/make_profiles.sh: the counter passes must run the plans the
+        // bench line ran, and the clock is different under counter collection); -1 = time as usual / no such kernel
+        const bool replay = S->plan_two >= -1 && S->plan_three >= -1 && (S->plan_two >= 0 || S->plan_three >= 0);
+        if (replay) {
+            if (S->plan_two >= 0) pair_shape = S->plan_two;
+            triple_alt = (S->plan_three >= 0 && fs::fused_supported<T>(S->tune, g, sc, 3)) ? S->plan_three : -1;
+            return FS_OK;
+        }
         auto consider2 = [&](int cand) -> int {
             float ms = 1e30f;
             int rc = timed(2, cand, &ms);
@@ -1392,6 +1402,12 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         const int n = atoi(value);
         if (n < (k == "mg_cycles" ? 0 : 1) || n > 1000) return fail(FS_EINVAL, "%s out of range", key);
         (k == "mg_cycles" ? s->mg_cycles : k == "mg_pre" ? s->mg_pre : k == "mg_post" ? s->mg_post : s->mg_coarse) = n;
+    } else if (k == "launch_plans") {
+        int two = -2, three = -2;
+        if (sscanf(value, "%d,%d", &two, &three) != 2 || two < -1 || three < -1 || two > 127 || three > 31)
+            return fail(FS_EINVAL, "launch_plans: \"<two-sweep plan id>,<three-sweep plan id>\" (-1 = none)");
+        s->plan_two = two;
+        s->plan_three = three;
     } else if (k == "sor_omega") {
         const float om = (float)atof(value);
         if (!(om > 0.0f && om < 2.0f)) return fail(FS_EINVAL, "sor_omega must lie in (0, 2)");

@@ -108,6 +108,8 @@ int fs_destroy(fs_sim* s);
  *                 column tables) | "row" (four cells per lane, clamp tables); all bit-identical, none faster by > 5 %;
  *   "mg_cycles" (default 4: 75 % of the time of the 80 sweeps of config 3, residual 34x smaller), "mg_pre", "mg_post" (smoothing steps before / after the coarse correction, default 1),
  *                 "mg_coarse_iters" (iterations on the coarsest level, default 30): solver "mg" only;
+ *   "launch_plans" "<two-sweep plan id>,<three-sweep plan id>" (what fs_get_int "pair_shape" / "triple_plan" reported
+ *                 in another run; -1 = none): replay those launch plans instead of timing candidates (profiling);
  *   "wall_free"   "auto" (default) | "0" | "1": whether workgroups of the three-sweep kernel that touch no wall run its
  *                 wall-free second body (auto: when a launch has more than 256 workgroups);
  *   "sweep_ry" "sweep_zc" "sweep_blocks" "pair_zc" "pair_shape" "project_kernels" "fuse_advect"
