@@ -15,7 +15,7 @@
 //   --grid WxHxD  --steps N  --acc N  --speed N  --dt F  --diff F
 //   --stl PATH[,scale,rot_x,rot_y,rot_z,tx,ty,tz]   (repeatable; "none" = no obstacle)
 //   --dump-every N (0 = never, -1 = last frame only)  --dump-dir DIR
-//   --precision fp32|fp64   --solver jacobi|gs_lex|rbsor   --omega W (rbsor)   --seed N   --quiet
+//   --precision fp32|fp64   --solver jacobi|gs_lex|rbsor|mg   --omega W (rbsor)   --mg-cycles N (mg)   --seed N   --quiet
 //   --resume DIR   start from the last frame of DIR/{data,obs,v_x,v_y,v_z}.bin (a dumped frame is
 //                  a complete state: everything else is rebuilt every step)
 //   --json         append one machine-readable timing line to stdout
@@ -113,12 +113,13 @@ int main(int argc, char** argv)
         if (key == "precision") { options.push_back({ "precision", val }); return true; }
         if (key == "solver") { options.push_back({ "solver", val }); return true; }
         if (key == "omega") { options.push_back({ "sor_omega", val }); return true; }
+        if (key == "mg-cycles") { options.push_back({ "mg_cycles", val }); return true; }
         if (key == "seed") { options.push_back({ "voxel_seed", val }); return true; }
         if (key == "resume") { resume_dir = val; return true; }
         return false;
     };
     static const char* const keys[] = { "grid", "steps", "acc", "speed", "dt", "diff", "stl", "dump-every", "dump-dir",
-                                        "precision", "solver", "omega", "seed", "resume" };
+                                        "precision", "solver", "omega", "mg-cycles", "seed", "resume" };
     for (const char* k : keys) {
         std::string env = "FS_";
         for (const char* p = k; *p; ++p) env += (*p == '-') ? '_' : (char)toupper(*p);
