@@ -1179,6 +1179,17 @@ template void launch_gradient<double>(hipStream_t, const SweepTune&, const GridD
 template <class T>
 __device__ __forceinline__ T clamp_ref(T v, T lo, T hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }   // std::clamp
 
+// The two x-neighbours of a trace's corner as ONE load: an element-aligned 2-vector (global memory takes 8- / 16-byte
+// loads at 4- / 8-byte alignment on this part).  A gather is paid per load instruction and distinct cache line, so four
+// loads per trace instead of eight is what matters here, not the bytes.
+typedef float pair_f __attribute__((ext_vector_type(2), aligned(4)));
+typedef double pair_d __attribute__((ext_vector_type(2), aligned(8)));
+template <class T> struct PairOf;
+template <> struct PairOf<float> { using type = pair_f; };
+template <> struct PairOf<double> { using type = pair_d; };
+template <class T>
+__device__ __forceinline__ typename PairOf<T>::type ld_pair(const T* p) { return *reinterpret_cast<const typename PairOf<T>::type*>(p); }
+
 template <class T>
 __device__ __forceinline__ T back_trace_tab(const GridDesc& g, const SlabCtx& sc, const T* __restrict__ src, long zshift,
                                             const T* __restrict__ tab, int x, int y, int z, T ux, T uy, T uz, T kx, T ky, T kz);
@@ -1214,10 +1225,11 @@ __global__ __launch_bounds__(256) void advect_kernel(GridDesc g, SlabCtx sc, int
         const int x0 = (int)floor(px), y0 = (int)floor(py), z0 = (int)floor(pz);
         const T tx = px - (T)x0, ty = py - (T)y0, tz = pz - (T)z0;
         const T* s = prev + prev_zshift + cell(g, x0, y0, z0 - sc.zoff);
-        const T a00 = s[0] * (one - tx) + s[1] * tx;                          // :412-415
-        const T a01 = s[g.sz] * (one - tx) + s[g.sz + 1] * tx;
-        const T a10 = s[g.sy] * (one - tx) + s[g.sy + 1] * tx;
-        const T a11 = s[g.sy + g.sz] * (one - tx) + s[g.sy + g.sz + 1] * tx;
+        const auto q00 = ld_pair(s), q01 = ld_pair(s + g.sz), q10 = ld_pair(s + g.sy), q11 = ld_pair(s + g.sy + g.sz);
+        const T a00 = q00.x * (one - tx) + q00.y * tx;                        // :412-415
+        const T a01 = q01.x * (one - tx) + q01.y * tx;
+        const T a10 = q10.x * (one - tx) + q10.y * tx;
+        const T a11 = q11.x * (one - tx) + q11.y * tx;
         const T b0 = a00 * (one - ty) + a10 * ty;                             // :417-418
         const T b1 = a01 * (one - ty) + a11 * ty;
         u = b0 * (one - tz) + b1 * tz;                                        // :420
@@ -1245,10 +1257,11 @@ __device__ __forceinline__ T back_trace(const GridDesc& g, const SlabCtx& sc, co
     const int x0 = (int)floor(px), y0 = (int)floor(py), z0 = (int)floor(pz);
     const T tx = px - (T)x0, ty = py - (T)y0, tz = pz - (T)z0;
     const T* s = src + zshift + cell(g, x0, y0, z0 - sc.zoff);
-    const T a00 = s[0] * (one - tx) + s[1] * tx;                          // :412-415
-    const T a01 = s[g.sz] * (one - tx) + s[g.sz + 1] * tx;
-    const T a10 = s[g.sy] * (one - tx) + s[g.sy + 1] * tx;
-    const T a11 = s[g.sy + g.sz] * (one - tx) + s[g.sy + g.sz + 1] * tx;
+    const auto q00 = ld_pair(s), q01 = ld_pair(s + g.sz), q10 = ld_pair(s + g.sy), q11 = ld_pair(s + g.sy + g.sz);
+    const T a00 = q00.x * (one - tx) + q00.y * tx;                        // :412-415
+    const T a01 = q01.x * (one - tx) + q01.y * tx;
+    const T a10 = q10.x * (one - tx) + q10.y * tx;
+    const T a11 = q11.x * (one - tx) + q11.y * tx;
     const T b0 = a00 * (one - ty) + a10 * ty;                             // :417-418
     const T b1 = a01 * (one - ty) + a11 * ty;
     return b0 * (one - tz) + b1 * tz;                                     // :420
@@ -1357,10 +1370,11 @@ __device__ __forceinline__ T back_trace_tab(const GridDesc& g, const SlabCtx& sc
         const int x0 = (int)floor(px);
         const T tx = px - (T)x0;
         const T* s = src + zshift + cell(g, x0, y0, z0 - sc.zoff);
-        a00 = s[0] * (one - tx) + s[1] * tx;                                  // :412-415
-        a01 = s[g.sz] * (one - tx) + s[g.sz + 1] * tx;
-        a10 = s[g.sy] * (one - tx) + s[g.sy + 1] * tx;
-        a11 = s[g.sy + g.sz] * (one - tx) + s[g.sy + g.sz + 1] * tx;
+        const auto q00 = ld_pair(s), q01 = ld_pair(s + g.sz), q10 = ld_pair(s + g.sy), q11 = ld_pair(s + g.sy + g.sz);
+        a00 = q00.x * (one - tx) + q00.y * tx;                                // :412-415
+        a01 = q01.x * (one - tx) + q01.y * tx;
+        a10 = q10.x * (one - tx) + q10.y * tx;
+        a11 = q11.x * (one - tx) + q11.y * tx;
     }
     const T b0 = a00 * (one - ty) + a10 * ty;                                 // :417-418
     const T b1 = a01 * (one - ty) + a11 * ty;
