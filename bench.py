@@ -13,7 +13,6 @@ For N>1 the driver launches one rank per GPU with torch.distributed.run; ranks e
 planes over RCCL inside libfluidsim.so.  Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
