@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Four steps of a benchmark workload under solver=mg, for a profiler to wrap:
+  rocprofv3 --kernel-trace --stats -d out -- python3 tools/mg_profile_run.py c3"""
 import os, sys, tempfile
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import fluid_simulation_amd as F
