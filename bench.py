@@ -141,7 +141,8 @@ def cpu_baseline(budget_s=10.0):
         n2, el2 = run_steps(sim, 1, 0.0)
         sim.close()
         out["value"] = W * H * D * n2 / el2
-        out["sample"] = ("256x256x256 tunnel, ball obstacle r=38, 40 iterations (BASELINE config 2's grid), 1 step in "
+        out["sample"] = ("256x256x256 tunnel, analytic ball obstacle r=38 (a numpy mask, not the STL sphere), 40 iterations "
+                         "(BASELINE config 2's grid), 1 step in "
                          "%.1f s, OpenMP %d threads, dumps off; config1 = 64x64x64 empty, 20 iterations, %d steps in %.1f s"
                          % (el2, cores, n_all, el_all))
     else:                                                # short form (tests): config 1 only
@@ -339,7 +340,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong" if world > 1 else None,   # one GPU: nothing scales (the N > 1 lines run config 4 strong-scaled)
         "vs_baseline": None,
         "dtype": "f64" if args.precision == "fp64" else "f32",
         "data": "synthetic",
@@ -356,6 +357,11 @@ def main():
         "roofline": {
             "kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            # the fraction that cannot exceed 1: measured HBM bytes per launch / launch time / peak (null without a PMC
+            # measurement of THIS build and launch plan); min_traffic_bytes = one read of iterate and right-hand side and
+            # one write of the result per launch, whatever the number of iterations applied on the way
+            "frac_physical": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k_n) else None,
+            "min_traffic_bytes": SWEEP_BYTES_PER_CELL * (elem // 4) * local_cells,
             "bytes_per_launch": bytes_per_launch, "solver_iterations_per_launch": iters_per_launch,
             "avg_launch_ms": avg_ms, "launches": k_n, "workgroup_shape_id": pair_shape,
             "launch_plan_three_sweeps": triple_plan, "two_sweep_kernel": two_name, "traffic_note": traffic_note,

@@ -1,4 +1,6 @@
-// comm.h -- z-slab communication over RCCL (xGMI), one process per GPU.
+// comm.h -- z-slab communication over RCCL (xGMI), one process per GPU; plus two development transports for hosts
+// with fewer GPUs than ranks: "FSIPC:" (ipc.h: stream-ordered device-to-device copies between rank processes, the
+// asynchronous one) and "FSSHM:" (host-staged and fully synchronous).
 //
 // The reference is single-process ("Distributed communication
 // backend: none"); this is new functionality.  z is the slowest memory axis
@@ -26,6 +28,7 @@
 #include <string>
 
 #include "kernels.h"
+#include "ipc.h"
 
 struct fs_sim;
 
@@ -178,6 +181,7 @@ struct Comm {
     ncclComm_t comm = nullptr;
     RcclApi* api = nullptr;
     ShmTransport* shm = nullptr;
+    IpcTransport* ipc = nullptr;   // "FSIPC:" ids (ipc.h)
     bool null_transport = false;   // "FSNULL:" ids: exchanges are skipped (compute-side timing of one slab; results invalid)
     std::string err;
 
@@ -185,6 +189,7 @@ struct Comm {
     const char* transport_name() const
     {
         return null_transport ? "none (FSNULL: timing only)" : shm ? "host shared memory (FSSHM: development)" :
+               ipc ? "device-to-device copies between rank processes (FSIPC: hipIpc-mapped arrays, stream-ordered)" :
                api ? api->path.c_str() : "none";
     }
     const char* last_error() const { return err.c_str(); }
@@ -219,6 +224,16 @@ struct Comm {
             nranks = nranks_;
             return 0;
         }
+        if (strncmp(idc, "FSIPC:", 6) == 0) {
+            if (nranks_ > IPC_MAXR) { err = "the FSIPC transport carries at most 8 ranks"; return -1; }
+            ipc = new IpcTransport;
+            ipc->name = std::string(idc + 6, strnlen(idc + 6, 120));
+            ipc->rank = rank_;
+            ipc->nranks = nranks_;
+            rank = rank_;
+            nranks = nranks_;
+            return 0;
+        }
         RcclApi& a = RcclApi::get(&err);
         if (!a.lib) return -1;
         api = &a;
@@ -235,6 +250,7 @@ struct Comm {
     {
         if (comm && api) api->CommDestroy(comm);
         if (shm) { shm->destroy(); delete shm; shm = nullptr; }
+        if (ipc) { ipc->destroy(); delete ipc; ipc = nullptr; }
         comm = nullptr;
         nranks = 1;
     }
@@ -249,6 +265,27 @@ struct Comm {
         hipError_t e_ = (call);                                               \
         if (e_ != hipSuccess) { err = hipGetErrorString(e_); return -1; }     \
     } while (0)
+
+    // Collective, FSIPC only: export allocation `slot` and map the peers' copies (neighbours, or all ranks for gather targets).
+    int register_buffer(int slot, void* base, size_t bytes, bool all_ranks)
+    {
+        if (!ipc || !active()) return 0;
+        return ipc->register_buffer(slot, base, bytes, all_ranks, &err);
+    }
+    // every rank has unmapped its peers' arrays: the owner may free them (FSIPC; call before the arrays are freed)
+    void release_buffers()
+    {
+        if (ipc) { ipc->destroy(); delete ipc; ipc = nullptr; null_transport = true; }
+    }
+    // a bounded device-side wait gave up (lost peer): the results since then are void
+    int check()
+    {
+        if (ipc && ipc->device_error()) {
+            err = "FSIPC: a device-side wait for a peer timed out at operation " + std::to_string(ipc->device_error());
+            return -1;
+        }
+        return 0;
+    }
 
     int shm_ready(const GridDesc& g, int Dglobal)
     {
@@ -282,6 +319,14 @@ struct Comm {
             FS_HIPC(hipStreamSynchronize(st));
             shm->barrier();
             return 0;
+        }
+        if (ipc) {
+            IpcTransport::Xfer x[2];
+            int peers[2], n = 0;
+            // my planes 1..depth land in the lower neighbour's planes D+1..D+depth, i.e. where I keep recv_hi
+            if (rank > 0) { x[n] = { rank - 1, send_lo, recv_hi, bytes }; peers[n++] = rank - 1; }
+            if (rank < nranks - 1) { x[n] = { rank + 1, send_hi, recv_lo, bytes }; peers[n++] = rank + 1; }
+            return ipc->exchange(st, x, n, peers, n, &err);
         }
         FS_NCCL(api->GroupStart());
         if (rank > 0) {
@@ -321,6 +366,7 @@ struct Comm {
             shm->barrier();
             return 0;
         }
+        if (ipc) return gather_window(st, src, dst, g, Dglobal, elem, Dglobal);   // a window that covers everything
         FS_NCCL(api->AllGather(s + plane, d + plane, plane * (size_t)g.D, ncclInt8, comm, st));
         FS_NCCL(api->Broadcast(s, d, plane, ncclInt8, 0, comm, st));
         FS_NCCL(api->Broadcast(s + (size_t)(g.D + 1) * plane, d + (size_t)(Dglobal + 1) * plane, plane, ncclInt8,
@@ -387,6 +433,23 @@ struct Comm {
             FS_HIPC(hipStreamSynchronize(st));
             shm->barrier();
             return 0;
+        }
+        if (ipc) {
+            // push: what rank j needs of my planes goes straight into j's gathered array (same layout as mine)
+            IpcTransport::Xfer x[IPC_MAXR];
+            int recv_peers[IPC_MAXR], n = 0, nrecv = 0;
+            for (int j = 0; j < nranks; ++j) {
+                if (j == rank) continue;
+                int wlo, whi, olo, ohi;
+                window(j, Dglobal, reach, wlo, whi);
+                int lo = wlo > ownlo ? wlo : ownlo, hi = whi < ownhi ? whi : ownhi;
+                if (lo <= hi) x[n++] = { j, s + (ptrdiff_t)(lo - zoff) * (ptrdiff_t)plane, d + (size_t)lo * plane, plane * (size_t)(hi - lo + 1) };
+                owned(j, Dglobal, olo, ohi);
+                lo = mylo > olo ? mylo : olo;
+                hi = myhi < ohi ? myhi : ohi;
+                if (lo <= hi) recv_peers[nrecv++] = j;
+            }
+            return ipc->exchange(st, x, n, recv_peers, nrecv, &err);
         }
         FS_NCCL(api->GroupStart());
         for (int j = 0; j < nranks; ++j) {
@@ -470,6 +533,11 @@ struct Comm {
             shm->barrier();
             return 0;
         }
+        if (ipc) {
+            if (ipc->open(&err)) return -1;
+            ipc->barrier();
+            return check();
+        }
         FS_NCCL(api->AllReduce(d_scratch1, d_scratch1, 1, ncclDouble, ncclSum, comm, st));
         FS_HIPC(hipStreamSynchronize(st));
         return 0;
@@ -499,6 +567,7 @@ struct Comm {
             FS_HIPC(hipStreamSynchronize(st));
             return 0;
         }
+        if (ipc) return ipc->reduce3(st, d3, &err);
         FS_NCCL(api->AllReduce(d3 + 0, d3 + 0, 1, ncclDouble, ncclSum, comm, st));
         FS_NCCL(api->AllReduce(d3 + 1, d3 + 1, 1, ncclDouble, ncclMin, comm, st));
         FS_NCCL(api->AllReduce(d3 + 2, d3 + 2, 1, ncclDouble, ncclMax, comm, st));

@@ -103,13 +103,26 @@ struct fs_sim {
     unsigned voxel_seed = 1;
     bool quiet = false, profile = false, elide_dead = false;
     bool fuse_advect = true;     // one kernel for the three velocity advections of a step (single GPU)
-    int overlap = 1;             // z-slabs: exchange boundary planes while the interior is computed (1: boundary launch, then
-                                 // interior launch, one stream; 2: boundary + exchange on the communication stream beside the interior)
+    int overlap = -1;            // z-slabs, how a pass and its halo exchange are scheduled: 0 the pass, then the exchange; 1 boundary
+                                 // planes first, their exchange on the communication stream while the interior is computed; 2 boundary
+                                 // launch + exchange on the communication stream beside the interior launch; -1 (default) = "auto":
+                                 // the three are timed once over the real transport, the slowest rank's time decides (all ranks agree)
+    int comm_cus = 0;            // z-slabs: CUs kept free of solver workgroups (the compute stream gets a CU mask) so that the
+                                 // transport's kernels find room beside a launch that fills the chip; -1 = "auto": 0 and 8 are timed
+    bool split_dens = true;      // z-slabs: run half of the (dead) density solve between the first projection and the velocity
+                                 // advection, so that the reach of the back-trace arrives on the host without stalling the device
+    // slab-step bookkeeping readable through fs_get_int
+    long n_stream_syncs = 0;     // host synchronisations of the compute stream issued by the slab step (reach fallback path)
+    long n_reach_waits = 0, n_reach_blocked = 0;   // waits for an asynchronously delivered reach; those that found it not yet there
+    double reach_wait_ms = 0.0;  // host time spent in them
+    int overlap_plan = -1, cus_plan = -1;          // what "auto" chose (or the forced values), -1 before the first slab solve
+    double overlap_ms[6] = {0, 0, 0, 0, 0, 0};     // slowest rank's ms per pass of each timed candidate (overlap 0/1/2 x cu mask off/on)
     bool debug_poison = false;   // fill the gathered advection source with NaN bit patterns before each gather
     int last_reach = 0;          // planes of reach used by the most recent slab advection
     // device
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_full = nullptr, stream_masked = nullptr;   // z-slabs with comm_cus: `stream` is one of these two
     EngineBase* eng = nullptr;
     // z-slab partition (comm.h)
     fs::Comm comm;
@@ -208,10 +221,23 @@ struct Engine : EngineBase {
     T* coltab = nullptr;                // clamp tables of the advection row kernels: 6 x (H+2)(D+2) (single GPU only)
     static constexpr int FUSED2 = 64;   // pair_shape >= FUSED2: the two-sweep passes run jacobi_fused_kernel<NL = 2>, plan id - FUSED2
     int pair_shape = -1;                // fastest two-sweep launch plan for this grid (timed once)
+    int pair_plan_rb = 0;               // fastest plan of jacobi_pair_kernel itself: its red-black / damped passes (rbsor, mg level 0)
+                                        // always run that kernel, also where the plain two-sweep passes went to the fused one
+    int tuned_plan_two = -3, tuned_plan_three = -3;   // "launch_plans" values the choices were made under
     int tuned_fuse = -1, tuned_pair_shape_opt = -1;   // option values the two choices here were timed under
     int triple_alt = -1;                // >= 0: three sweeps per pass beat two on this grid (launch plan id)
-    hipStream_t comm_stream = nullptr;  // halo exchanges that overlap interior compute (z-slabs)
-    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_int = nullptr;
+    hipStream_t comm_stream = nullptr;  // z-slabs: EVERY transport call runs on this one stream (a communicator is never driven from
+                                        // two streams); events order it against the compute stream
+    hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_int = nullptr, ev_c2x = nullptr;
+    // z-slabs: the reach of the advection back-trace without a host synchronisation.  max |v_z| after each of the step's two
+    // projections is reduced over the ranks and copied to pinned memory asynchronously; the host waits for the EVENT behind the copy
+    // when it sizes the gather, by which time the device has long passed it (see step()).
+    double* reach_pinned = nullptr;     // 2 x {sum, min, max}
+    hipEvent_t ev_reach[2] = {nullptr, nullptr};
+    bool reach_posted[2] = {false, false};
+    double vzmax_prev = -1.0;           // max |v_z| at the end of the previous step (= v_z_prev of this one), -1 = unknown
+    bool in_step = false;               // inside step(): the data flow between the solver's calls is known
+    static constexpr int SLOT_GATHER = NPOOL;   // FSIPC export slots: the pool arrays, then the gathered advection sources
     static constexpr int NRED = 3 * 1024 + 12;   // reduction scratch + up to four {sum, min, max} results
 
     explicit Engine(fs_sim* s) : S(s) {}
@@ -267,10 +293,44 @@ struct Engine : EngineBase {
             int lo_pri = 0, hi_pri = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
             HIP_TRY(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, hi_pri));
-            HIP_TRY(hipEventCreateWithFlags(&ev_edges, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ev_int, hipEventDisableTiming));
+            for (hipEvent_t* ev : { &ev_edges, &ev_halo, &ev_int, &ev_c2x, &ev_reach[0], &ev_reach[1] })
+                HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+            HIP_TRY(hipHostMalloc((void**)&reach_pinned, 6 * sizeof(double), hipHostMallocDefault));
+            // FSIPC: the neighbours write straight into these arrays
+            for (int i = 0; i < NPOOL; ++i)
+                if (S->comm.register_buffer(i, arr[i] - g.lead, g.n * sizeof(T), false))
+                    return fail(FS_ECOMM, "exporting the field arrays: %s", S->comm.last_error());
+            if (S->comm_cus != 0) {
+                // a second compute stream whose CU mask leaves CUs to the transport; mask bit i is CU i / 8 of XCD i % 8 (the
+                // driver deals the bits round-robin over the XCDs), so clearing the top bits takes the same number from every XCD
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, S->device));
+                const int ncu = prop.multiProcessorCount;
+                int keep_free = S->comm_cus > 0 ? S->comm_cus : 8;
+                if (keep_free > ncu / 2) keep_free = ncu / 2;
+                std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+                for (int i = 0; i < ncu - keep_free; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+                HIP_TRY(hipExtStreamCreateWithCUMask(&S->stream_masked, (uint32_t)mask.size(), mask.data()));
+                S->stream_full = S->stream;
+                masked_cus = ncu - keep_free;
+                if (S->comm_cus > 0) use_masked_stream(true);      // forced; "auto" decides with the overlap plan
+            }
         }
+        return FS_OK;
+    }
+
+    int masked_cus = 0;
+    // switch the compute stream (everything queued on the old one first completes)
+    int use_masked_stream(bool on)
+    {
+        hipStream_t want = on ? S->stream_masked : S->stream_full;
+        if (!want || want == S->stream) return FS_OK;
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        S->resolve_spans();
+        S->stream = want;
+        S->tune.cu_slots = on ? masked_cus : 256;
+        S->cus_plan = on ? (S->comm_cus > 0 ? S->comm_cus : 8) : 0;
+        pair_shape = -1;                                 // the launch plans depend on how many CUs a launch can fill
         return FS_OK;
     }
 
@@ -287,9 +347,9 @@ struct Engine : EngineBase {
         if (red) hipFree(red);
         if (coltab) hipFree(coltab);
         mg.release();
-        if (ev_edges) hipEventDestroy(ev_edges);
-        if (ev_halo) hipEventDestroy(ev_halo);
-        if (ev_int) hipEventDestroy(ev_int);
+        for (hipEvent_t ev : { ev_edges, ev_halo, ev_int, ev_c2x, ev_reach[0], ev_reach[1] })
+            if (ev) hipEventDestroy(ev);
+        if (reach_pinned) hipHostFree(reach_pinned);
         if (comm_stream) hipStreamDestroy(comm_stream);
     }
 
@@ -382,8 +442,8 @@ struct Engine : EngineBase {
         else if (levels == 2 && !rb && pair_shape >= FUSED2)
             fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 2, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape - FUSED2, second);
         else if (levels == 2)
-            fs::launch_jacobi_pair<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape, second, omega,
-                                      rb_damped);
+            fs::launch_jacobi_pair<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl,
+                                      pair_shape >= FUSED2 ? pair_plan_rb : pair_shape, second, omega, rb_damped);
         else
             fs::launch_jacobi<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, second);
     }
@@ -395,9 +455,13 @@ struct Engine : EngineBase {
     {
         if (!two_sweep_kernels() && !fs::fused_supported<T>(S->tune, g, sc, 3)) return FS_OK;
         const int opt = S->tune.pair_shape + 16 * S->tune.two_kind;
-        if (pair_shape >= 0 && tuned_fuse == S->tune.fuse && tuned_pair_shape_opt == opt) return FS_OK;
+        if (pair_shape >= 0 && tuned_fuse == S->tune.fuse && tuned_pair_shape_opt == opt && tuned_plan_two == S->plan_two &&
+            tuned_plan_three == S->plan_three)
+            return FS_OK;
         tuned_fuse = S->tune.fuse;
         tuned_pair_shape_opt = opt;
+        tuned_plan_two = S->plan_two;
+        tuned_plan_three = S->plan_three;
         return choose_pair_shape(cur, rhs, b, a, inv_c);
     }
 
@@ -531,7 +595,30 @@ struct Engine : EngineBase {
     int choose_pair_shape(int src, int rhs, int b, T a, T inv_c)
     {
         pair_shape = 0;
+        pair_plan_rb = 0;
         triple_alt = -1;
+        // "launch_plans" = "<two-sweep id>,<three-sweep id>" (as fs_get_int "pair_shape" / "triple_plan" report them): replay
+        // the plans of another run instead of timing (tools/make_profiles.sh: the counter passes must run the plans the
+        // bench line ran, and the clock is different under counter collection); -1 = time as usual / no such kernel.
+        // An id that names a kernel or shape this grid does not have is refused, not run.
+        const bool replay = S->plan_two >= -1 && S->plan_three >= -1 && (S->plan_two >= 0 || S->plan_three >= 0);
+        if (replay) {
+            if (S->plan_two >= FUSED2) {
+                const int id = S->plan_two - FUSED2;
+                if (!fs::fused_supported<T>(S->tune, g, sc, 2) || (id & 7) >= fs::fused_shape_count<T>(g, 2) || (id >> 3) > 2)
+                    return fail(FS_EINVAL, "launch_plans: two-sweep plan %d names a fused-kernel shape this grid does not have", S->plan_two);
+            } else if (S->plan_two >= 0) {
+                if (!fs::pair_supported<T>(S->tune, g, sc) || (S->plan_two & 7) >= fs::pair_shape_count<T>(g) || (S->plan_two >> 3) > 2)
+                    return fail(FS_EINVAL, "launch_plans: two-sweep plan %d names a pair-kernel shape this grid does not have", S->plan_two);
+            }
+            if (S->plan_three >= 0 && fs::fused_supported<T>(S->tune, g, sc, 3) &&
+                ((S->plan_three & 7) >= fs::fused_shape_count<T>(g, 3) || (S->plan_three >> 3) > 2))
+                return fail(FS_EINVAL, "launch_plans: three-sweep plan %d names a shape this grid does not have", S->plan_three);
+            if (S->plan_two >= 0) pair_shape = S->plan_two;
+            if (pair_shape < FUSED2) pair_plan_rb = pair_shape;
+            triple_alt = (S->plan_three >= 0 && fs::fused_supported<T>(S->tune, g, sc, 3)) ? S->plan_three : -1;
+            return FS_OK;
+        }
         int tmp = acquire(src, rhs);
         if (tmp < 0) return fail(FS_ENOMEM, "array pool exhausted");
         struct Release {                                   // error paths must not leak the scratch arrays or the events
@@ -569,17 +656,8 @@ struct Engine : EngineBase {
                         sizeof(T) == 8 ? "fp64" : "fp32", levels, cand, *ms);
             return rc;
         };
-        float best = 1e30f;
+        float best = 1e30f, best_pair = 1e30f;
         int best_cand = -1;
-        // "launch_plans" = "<two-sweep id>,<three-sweep id>" (as fs_get_int "pair_shape" / "triple_plan" report them): replay
-        // the plans of another run instead of timing (tools/make_profiles.sh: the counter passes must run the plans the
-        // bench line ran, and the clock is different under counter collection); -1 = time as usual / no such kernel
-        const bool replay = S->plan_two >= -1 && S->plan_three >= -1 && (S->plan_two >= 0 || S->plan_three >= 0);
-        if (replay) {
-            if (S->plan_two >= 0) pair_shape = S->plan_two;
-            triple_alt = (S->plan_three >= 0 && fs::fused_supported<T>(S->tune, g, sc, 3)) ? S->plan_three : -1;
-            return FS_OK;
-        }
         auto consider2 = [&](int cand) -> int {
             float ms = 1e30f;
             int rc = timed(2, cand, &ms);
@@ -587,6 +665,7 @@ struct Engine : EngineBase {
             // a later candidate has to win by 1.5 %: plans within the noise of each other must not flip from run to run
             // (the chosen plan is part of what profiles/sweep_traffic.json is stamped with)
             if (ms < best * 0.985f) { best = ms; best_cand = cand; }
+            if (cand < FUSED2 && ms < best_pair * 0.985f) { best_pair = ms; pair_plan_rb = cand; }
             return FS_OK;
         };
         // options: pair_shape > 0 forces a workgroup shape of the pair kernel, two_sweep_kernel one of the two kernels

@@ -45,6 +45,8 @@ struct SweepTune {
     int zc_len = 0;           // planes per z chunk; 0 = derive from target_blocks
     int target_blocks = 2048; // aim for about this many workgroups per launch
     int abl = 0;
+    int cu_slots = 256;       // CUs a launch of this handle can fill (fewer when the compute stream carries a CU mask, z-slabs with
+                              // "comm_cus"): what the launchers' z-chunk models divide the workgroups over
     int fuse = 3;             // sweeps fused per pass over memory: 1 never, 2 two-sweep kernels only, 3 (default) also time the
                               // three-sweep kernel per grid and use it where a sweep costs less, 4 use it wherever it exists
     int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic

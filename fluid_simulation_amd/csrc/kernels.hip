@@ -545,7 +545,7 @@ static void launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc&
     // because how the block count falls against the 256 CUs matters more than the model knows)
     int cand_nzc[3] = {1, 1, 1};
     double cand_eff[3] = {-1.0, -1.0, -1.0};
-    const int slots = 256;
+    const int slots = tune.cu_slots > 0 ? tune.cu_slots : 256;
     for (int nzc = 1; nzc <= 64 && (nzc == 1 || planes / nzc >= 12); ++nzc) {
         const long blocks = (long)nbands * nzc;
         const long rounds = (blocks + slots - 1) / slots;

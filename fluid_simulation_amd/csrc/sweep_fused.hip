@@ -455,7 +455,7 @@ static void launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc
         // count by this model (the host driver times alt = 0, 1, 2 once per grid).
         int cand_nzc[3] = {1, 1, 1};
         double cand_eff[3] = {-1.0, -1.0, -1.0};
-        const int slots = 256;
+        const int slots = tune.cu_slots > 0 ? tune.cu_slots : 256;
         for (int nzc = 1; nzc <= 64 && (nzc == 1 || planes / nzc >= 16); ++nzc) {
             const long blocks = (long)nbands * nzc;
             const long rounds = (blocks + slots - 1) / slots;

@@ -202,9 +202,11 @@ class Simulation:
 def comm_unique_id(transport="rccl"):
     """128-byte id for fs_comm_init.  "rccl": an ncclUniqueId (RCCL over xGMI, one GPU per rank).
     "shm": a host-staged development transport through POSIX shared memory, for ranks that
-    are processes on one host and may share a GPU (tests on a 1-GPU box)."""
-    if transport == "shm":
-        name = "FSSHM:/fs_slab_%d_%s" % (os.getpid(), os.urandom(4).hex())
+    are processes on one host and may share a GPU (tests on a 1-GPU box).
+    "ipc": a stream-ordered device-to-device transport between rank processes of one host (hipIpc-mapped
+    arrays, copy engines, device-side handshakes; ranks may share a GPU) -- csrc/ipc.h."""
+    if transport in ("shm", "ipc"):
+        name = "%s:/fs_slab_%d_%s" % ("FSSHM" if transport == "shm" else "FSIPC", os.getpid(), os.urandom(4).hex())
         return name.encode().ljust(_lib.COMM_ID_BYTES, b"\0")
     buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
     check(_lib.lib().fs_comm_unique_id(buf))

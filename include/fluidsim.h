@@ -85,6 +85,9 @@ int fs_destroy(fs_sim* s);
  *                 reference's in-place lexicographic sweep, simulation.cpp:259-271, bit-identical with
  *                 the reference at one OpenMP thread; single GPU) | "rbsor" (optional red-black SOR,
  *                 different arithmetic from the reference by design; defined by oracle/cpu_ref.c CR_RBSOR)
+ *                 | "mg" (optional: the projection's pressure equation solved by multigrid V-cycles, every
+ *                 other system relaxed as under "jacobi"; different arithmetic from the reference by design,
+ *                 defined by oracle/cpu_ref_mg.h CR_MG; see FS_SOLVER_MG above)
  *   "sor_omega"   relaxation factor of "rbsor", in (0, 2), default 1 (= red-black Gauss-Seidel)
  *   "dump_dir"    directory for frame dumps, default "data" (simulation.cpp:56-60)
  *   "dump_every"  N>=1 dump every Nth step (default 1 = reference behaviour), 0 = never,
@@ -177,8 +180,10 @@ int fs_field_stats(fs_sim* s, int which, double* sum, double* min, double* max);
 
 /* With option "profile"="1": accumulated HIP-event time and launch count of one kernel
  * family since the last fs_reset_timing: "sweep" (one solver iteration per launch)
- * "sweep_pair" (two iterations per launch) "divergence" "gradient" "advect" "bounds" "misc"
- * "comm".  Events are recorded on the handle's own stream. */
+ * "sweep_pair" (two iterations per launch) "sweep_triple" (three iterations per launch)
+ * "divergence" "gradient" "advect" "bounds" "misc" "comm" (z-slab exchanges and gathers)
+ * "multigrid" (the coarse-level work of solver "mg"; its level-0 smoothing passes count as
+ * "sweep_pair").  Events are recorded on the handle's own stream. */
 int fs_get_timing(fs_sim* s, const char* family, double* total_ms, long* launches);
 int fs_reset_timing(fs_sim* s);
 

@@ -643,3 +643,60 @@ def test_config4_one_step_at_full_1024x512x512(F, oracle_mod):
         del got
     sim.close()
     ora.close()
+
+
+def test_config3_full_80_sweep_diffusion_solve_and_whole_step(F, oracle_mod, tmp_path):
+    """BASELINE config 3 exactly, the solves the pressure test above does not reach: 512^3 with the benchmark's own
+    STL mask and 80 iterations, from a seeded random velocity state --
+      (1) ONE full velocity diffusion `diffuse(1, v_x, v_x_prev)` (simulation.cpp:278-284: a = dt*diff*W*H*D = 134.2,
+          c = 1 + 6a; b = 1: negated x-inlet ghost face, every cell next to a solid zeroed after every sweep), the
+          26 three-sweep launches + 1 two-sweep launch bench.py times, chained;
+      (2) then ONE whole step (simulation.cpp:96-150) at 80 iterations: the three diffusions start from the aliased
+          snapshot (v_prev = v is a pointer alias here, so the first pass reads iterate and right-hand side from one
+          array), b = 1, 2, 3 ghost faces, both projections, all four advections on a rough flow, the dead density solve.
+    Against the oracle's Jacobi (about two minutes on 16 host threads), every field bit-identical."""
+    O = oracle_mod
+    W = H = D = 512
+    sim = F.Simulation(W, H, D, 1, acc=80, quiet=1, voxel_seed=1)
+    ora = O.Oracle(W, H, D, solver=O.JACOBI, acc=80, threads=O.default_threads(16))
+    _bench_obstacles(F, O, sim, ora, W, tmp_path, True, 1)
+    rng = np.random.default_rng(512080)
+    for f in (F.VX, F.VY, F.VZ, F.DENS):
+        a = _random_field(rng, (D + 2, H + 2, W + 2))
+        if f == F.DENS:
+            a = np.abs(a)
+        for s in (sim, ora):
+            s.set(f, a)
+            if f == F.VX:
+                s.set(F.VX_PREV, a)
+        del a
+    sim.diffuse(1, F.VX, F.VX_PREV)
+    assert sim._geti("triple_plan") >= 0, "the three-sweep kernel was expected to be selected at 512^3"
+    ora.diffuse(1, F.VX, F.VX_PREV)
+    assert_same(sim.get(F.VX), ora.get(F.VX), "config 3, 80-sweep diffusion of v_x (b = 1)")
+    sim.run_one()
+    ora.run_one()
+    for f in (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE, F.DIVERGENCE):
+        assert_same(sim.get(f), ora.get(f), "config 3, whole step at 80 iterations: " + F.FIELD_NAMES[f])
+    sim.close()
+    ora.close()
+
+
+def test_config1_exactly_gs_lex_matches_the_reference(F, oracle_mod):
+    """BASELINE config 1 exactly -- 64^3 empty tunnel, 50 steps, 20 solver iterations, constructor defaults
+    (simulation.h:60-64) -- in the reference's own sweep order (solver=gs_lex) against the compiled, unmodified
+    reference at one thread (oracle/_ref/libref.so; where it did not travel, the C restatement in the same mode,
+    which tests/test_oracle_vs_ref.py pins to it): the five dumped fields (simulation.cpp:140-148) bit-identical
+    after every tenth step and at the end."""
+    O = oracle_mod
+    N, steps, acc = 64, 50, 20
+    sim = F.Simulation(N, N, N, steps, acc=acc, solver="gs_lex", quiet=1, dump_every=0)
+    ref = O.Reference(N, N, N, threads=1, iter=steps, acc=acc) if O.have_reference() else O.Oracle(N, N, N, solver=O.GS_LEX, threads=1, iter=steps, acc=acc)
+    for i in range(steps):
+        sim.run_one()
+        ref.run_one()
+        if (i + 1) % 10 == 0:
+            for f in (F.DENS, F.OBS, F.VX, F.VY, F.VZ):
+                assert_same(sim.get(f), ref.get(f), "config 1, step %d: %s" % (i + 1, F.FIELD_NAMES[f]))
+    sim.close()
+    ref.close()
