@@ -154,10 +154,11 @@ def cpu_baseline(budget_s=10.0):
 
 
 def slab_parity_check(F, fsdist, dist, rank, world, transport, ctl_device):
-    """N>1 only, before the timed run: every rank runs a small tunnel twice -- whole on its own
-    GPU, and as its z-slab of a world-wide run over the real transport (RCCL) -- and compares
-    its planes of every field bit for bit.  This is the multi-rank RCCL parity test that a
-    one-GPU box cannot run (tests/test_gpu_slabs.py does the same over shared memory)."""
+    """N>1 only, before the timed run: every rank runs a small tunnel whole on its own GPU, then as its z-slab of
+    a world-wide run over the real transport -- once per communication schedule (overlap = auto, 0, 1, 2: "auto" times
+    the other three and every rank must come out with the same one) -- and compares its planes of every field bit for
+    bit.  This is the multi-rank parity test over RCCL that a one-GPU box cannot run (tests/test_gpu_slabs.py does the
+    same over the two development transports)."""
     import numpy as np
     W, H, acc, steps = 96, 40, 7, 3
     D = 16 * world                                       # 16 planes per rank: deep enough for the boundary-first overlapped exchange
@@ -166,31 +167,42 @@ def slab_parity_check(F, fsdist, dist, rank, world, transport, ctl_device):
     mask[0] = mask[-1] = False
     mask[:, 0] = mask[:, -1] = False
     mask[:, :, 0] = mask[:, :, -1] = False
+    fields = (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE, F.DIVERGENCE)
     whole = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0)
     whole.set_mask(mask)
-    slab = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0)
-    uid = fsdist.share_unique_id(dist, lambda: F.comm_unique_id(transport), rank, device=ctl_device)
-    slab.comm_init(rank, world, uid)
-    dl, zoff = slab.local_depth, slab.z_offset
-    slab.set_mask(mask[zoff:zoff + dl + 2])
     for _ in range(steps):
         whole.run_one()
-        slab.run_one()
-    bad = []
-    for f in (F.DENS, F.VX, F.VY, F.VZ, F.PRESSURE, F.DIVERGENCE):
-        a = whole.get(f)[zoff + 1:zoff + dl + 1]
-        b = slab.get(f)[1:dl + 1]
-        if a.tobytes() != b.tobytes():
-            bad.append(F.FIELD_NAMES[f])
-    ss, ws = slab.stats(F.VX), whole.stats(F.VX)         # (sum, min, max) over the global grid on every rank
-    stats_ok = ss[1:] == ws[1:] and abs(ss[0] - ws[0]) <= 1e-9 * max(1.0, abs(ws[0]))
-    slab.close()
+    want = {f: whole.get(f) for f in fields}
+    ws = whole.stats(F.VX)                               # (sum, min, max) over the global grid
     whole.close()
-    flag = fsdist.max_over_ranks(dist, 1.0 if (bad or not stats_ok) else 0.0, device=ctl_device)
-    if bad or not stats_ok:
-        sys.stderr.write("rank %d: z-slab run differs from the single-GPU run in %s (stats ok: %s)\n" % (rank, bad, stats_ok))
-    return {"ok": flag == 0.0, "grid": [W, H, D], "steps": steps, "acc": acc,
-            "what": "every rank: its planes of dens/v/p/div of a %d-rank slab run vs the same run whole on its own GPU, bit-exact" % world}
+    bad, schedules = [], {}
+    for overlap in ("auto", "0", "1", "2"):
+        slab = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0, overlap=overlap)
+        uid = fsdist.share_unique_id(dist, lambda: F.comm_unique_id(transport), rank, device=ctl_device)
+        slab.comm_init(rank, world, uid)
+        dl, zoff = slab.local_depth, slab.z_offset
+        slab.set_mask(mask[zoff:zoff + dl + 2])
+        for _ in range(steps):
+            slab.run_one()
+        for f in fields:
+            if want[f][zoff + 1:zoff + dl + 1].tobytes() != slab.get(f)[1:dl + 1].tobytes():
+                bad.append("%s (overlap=%s)" % (F.FIELD_NAMES[f], overlap))
+        ss = slab.stats(F.VX)
+        if not (ss[1:] == ws[1:] and abs(ss[0] - ws[0]) <= 1e-9 * max(1.0, abs(ws[0]))):
+            bad.append("stats (overlap=%s)" % overlap)
+        plan = slab._geti("overlap_plan")
+        if fsdist.max_over_ranks(dist, float(plan), device=ctl_device) != -fsdist.max_over_ranks(dist, -float(plan), device=ctl_device):
+            bad.append("ranks disagree on the schedule (overlap=%s)" % overlap)
+        if slab._geti("stream_syncs") != 0:
+            bad.append("a slab step synchronised the compute stream (overlap=%s)" % overlap)
+        schedules[overlap] = plan
+        slab.close()
+    flag = fsdist.max_over_ranks(dist, 1.0 if bad else 0.0, device=ctl_device)
+    if bad:
+        sys.stderr.write("rank %d: z-slab run differs from the single-GPU run: %s\n" % (rank, bad))
+    return {"ok": flag == 0.0, "grid": [W, H, D], "steps": steps, "acc": acc, "schedule_run_under_overlap": schedules,
+            "what": "every rank: its planes of dens/v/p/div of a %d-rank slab run vs the same run whole on its own GPU, bit-exact, "
+                    "once per communication schedule (auto, 0, 1, 2)" % world}
 
 
 def main():
@@ -207,9 +219,14 @@ def main():
     ap.add_argument("--launch-plans", default=None,
                     help="\"<two-sweep plan id>,<three-sweep plan id>\": replay the launch plans of another run instead of timing "
                          "them (tools/make_profiles.sh: counter passes must run what the bench line ran)")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "shm"],
-                    help="shm: development rehearsal of the N>1 path on fewer GPUs than ranks (host-staged "
-                         "halo planes through shared memory, torch.distributed over gloo); never a result")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "ipc", "shm"],
+                    help="rccl (default): halo planes over RCCL/xGMI, one GPU per rank.  ipc: stream-ordered device-to-device "
+                         "copies between the rank processes (csrc/ipc.h); with one GPU per rank an alternative to RCCL, with "
+                         "fewer GPUs than ranks a development rehearsal (ranks share GPUs; never a result).  shm: the host-"
+                         "staged synchronous development transport; never a result")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "0", "1", "2"],
+                    help="communication schedule of the slab passes (fs_set_option \"overlap\"); auto = timed over the real transport")
+    ap.add_argument("--comm-cus", default="0", help="CUs kept free of solver workgroups for the transport: 0 (default), N, or auto")
     args = ap.parse_args()
 
     import torch
@@ -223,7 +240,7 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); the solver has no CPU path")
-    rehearsal = args.transport == "shm"
+    rehearsal = args.transport == "shm" or (args.transport == "ipc" and torch.cuda.device_count() < world)
     if rehearsal:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -255,7 +272,8 @@ def main():
         from fluid_simulation_amd import dist as fsdist
         slab_parity = slab_parity_check(F, fsdist, dist, rank, world, args.transport, ctl_device)
 
-    sim = F.Simulation(W, H, D, args.steps, acc=acc, precision=args.precision, quiet=1, dump_every=0, profile=1)
+    sim = F.Simulation(W, H, D, args.steps, acc=acc, precision=args.precision, quiet=1, dump_every=0, profile=1,
+                       overlap=args.overlap, comm_cus=args.comm_cus)
     if args.launch_plans:
         sim.set_option("launch_plans", args.launch_plans)
     if world > 1:
@@ -348,8 +366,9 @@ def main():
             "workload": "%s: %dx%dx%d wind tunnel, %s, %d solver iterations per solve, Jacobi, dumps off"
                         % (name, W, H, D, "sphere + plate STL obstacles" if cfg["plate"] else "sphere STL obstacle", acc),
             "grid": [W, H, D], "acc": acc, "solver": "jacobi",
-            "parallelism": ("z-slabs x%d, %s" % (world, "REHEARSAL over host shared memory (not a result)" if rehearsal
-                                                  else "RCCL halo exchange over xGMI")) if world > 1 else "single GPU",
+            "parallelism": ("z-slabs x%d, %s" % (world, "REHEARSAL, ranks share GPUs (not a result)" if rehearsal
+                                                  else "RCCL halo exchange over xGMI" if args.transport == "rccl"
+                                                  else "device-to-device copies between rank processes (FSIPC)")) if world > 1 else "single GPU",
             "voxelizer_points_added": added,
             "halo_transport": sim.comm_transport(),
         },
@@ -371,6 +390,18 @@ def main():
         },
         "kernel_ms": {k: {"total_ms": v[0], "launches": v[1]} for k, v in fam.items()},
         "slab_parity": slab_parity,
+        # N > 1: the communication schedule the run used (overlap "auto" = timed over the real transport, the slowest
+        # rank's time per pass of each candidate decides) and what the slab steps cost the host
+        "comm": None if world == 1 else {
+            "overlap_plan": sim._geti("overlap_plan"), "comm_cus": sim._geti("comm_cus_plan"),
+            "candidates_ms_per_pass": {"overlap=%d%s" % (k % 3, ", CU mask" if k >= 3 else ""): sim._getf("overlap%d_ms" % k)
+                                       for k in range(6) if sim._getf("overlap%d_ms" % k) > 0},
+            "comm_family_ms_per_step": fam["comm"][0] / args.steps,
+            "comm_family_note": "halo refreshes outside the solver, advection gathers and reductions, waits included; the "
+                                "solver's own exchanges fall inside the sweep families",
+            "stream_syncs": sim._geti("stream_syncs"), "reach_waits": sim._geti("reach_waits"),
+            "reach_waits_blocked": sim._geti("reach_waits_blocked"), "reach_wait_us": sim._geti("reach_wait_us"),
+        },
         "step_bytes_per_cell_algorithmic": 208 + 72 * acc,
         "step_roofline_frac": (208 + 72 * acc) * (elem // 4) * cells * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
     }

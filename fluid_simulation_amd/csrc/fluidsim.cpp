@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -232,13 +233,14 @@ struct Engine : EngineBase {
     // z-slabs: the reach of the advection back-trace without a host synchronisation.  max |v_z| after each of the step's two
     // projections is reduced over the ranks and copied to pinned memory asynchronously; the host waits for the EVENT behind the copy
     // when it sizes the gather, by which time the device has long passed it (see step()).
-    double* reach_pinned = nullptr;     // 2 x {sum, min, max}
-    hipEvent_t ev_reach[2] = {nullptr, nullptr};
-    bool reach_posted[2] = {false, false};
+    double* reach_pinned = nullptr;     // 3 x {sum, min, max}: after the first / second projection, at the start of the step
+    hipEvent_t ev_reach[3] = {nullptr, nullptr, nullptr};
+    bool reach_posted[3] = {false, false, false};
     double vzmax_prev = -1.0;           // max |v_z| at the end of the previous step (= v_z_prev of this one), -1 = unknown
+    double vzmax_end = -1.0;            // the same for the step that is running
     bool in_step = false;               // inside step(): the data flow between the solver's calls is known
     static constexpr int SLOT_GATHER = NPOOL;   // FSIPC export slots: the pool arrays, then the gathered advection sources
-    static constexpr int NRED = 3 * 1024 + 12;   // reduction scratch + up to four {sum, min, max} results
+    static constexpr int NRED = 3 * 1024 + 18;   // reduction scratch + up to six {sum, min, max} results (0, 1: stats / trace_reach; 2..4: post_vzmax)
 
     explicit Engine(fs_sim* s) : S(s) {}
 
@@ -293,9 +295,9 @@ struct Engine : EngineBase {
             int lo_pri = 0, hi_pri = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
             HIP_TRY(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, hi_pri));
-            for (hipEvent_t* ev : { &ev_edges, &ev_halo, &ev_int, &ev_c2x, &ev_reach[0], &ev_reach[1] })
+            for (hipEvent_t* ev : { &ev_edges, &ev_halo, &ev_int, &ev_c2x, &ev_reach[0], &ev_reach[1], &ev_reach[2] })
                 HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-            HIP_TRY(hipHostMalloc((void**)&reach_pinned, 6 * sizeof(double), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void**)&reach_pinned, 9 * sizeof(double), hipHostMallocDefault));
             // FSIPC: the neighbours write straight into these arrays
             for (int i = 0; i < NPOOL; ++i)
                 if (S->comm.register_buffer(i, arr[i] - g.lead, g.n * sizeof(T), false))
@@ -347,7 +349,7 @@ struct Engine : EngineBase {
         if (red) hipFree(red);
         if (coltab) hipFree(coltab);
         mg.release();
-        for (hipEvent_t ev : { ev_edges, ev_halo, ev_int, ev_c2x, ev_reach[0], ev_reach[1] })
+        for (hipEvent_t ev : { ev_edges, ev_halo, ev_int, ev_c2x, ev_reach[0], ev_reach[1], ev_reach[2] })
             if (ev) hipEventDestroy(ev);
         if (reach_pinned) hipHostFree(reach_pinned);
         if (comm_stream) hipStreamDestroy(comm_stream);
@@ -409,10 +411,7 @@ struct Engine : EngineBase {
         if (!flags_dirty) return FS_OK;
         int rc = unalias(FS_OBS);
         if (rc) return rc;
-        if (S->comm.active()) {
-            rc = S->comm.exchange_halo(S->stream, arr[slot[FS_OBS]], g, sizeof(T), S->D, g.zh);
-            if (rc) return fail(FS_ECOMM, "halo exchange of obs failed: %s", S->comm.last_error());
-        }
+        if (S->comm.active() && (rc = halo(arr[slot[FS_OBS]]))) return rc;
         ScopedSpan sp(S, FAM_MISC);
         fs::launch_build_flags<T>(S->stream, g, sc, arr[slot[FS_OBS]], flags);
         fs::launch_build_kill(S->stream, g, sc, flags, kill);
@@ -421,13 +420,26 @@ struct Engine : EngineBase {
         return FS_OK;
     }
 
+    // Every transport call of a slab rank goes through here: queued on the communication stream behind everything the
+    // compute stream holds so far, and the compute stream continues behind it.  One stream per communicator: RCCL orders a
+    // communicator's operations by issue order, and two streams sharing one would be serialised in ways the schedule
+    // does not show (round-2 verdict).
+    template <class F>
+    int comm_op(F&& op, const char* what)
+    {
+        HIP_TRY(hipEventRecord(ev_c2x, S->stream));
+        HIP_TRY(hipStreamWaitEvent(comm_stream, ev_c2x, 0));
+        if (op(comm_stream)) return fail(FS_ECOMM, "%s failed: %s", what, S->comm.last_error());
+        HIP_TRY(hipEventRecord(ev_halo, comm_stream));
+        HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
+        return FS_OK;
+    }
+
     int halo(T* a)
     {
         if (!S->comm.active()) return FS_OK;
         ScopedSpan sp(S, FAM_COMM);
-        int rc = S->comm.exchange_halo(S->stream, a, g, sizeof(T), S->D, g.zh);
-        if (rc) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
-        return FS_OK;
+        return comm_op([&](hipStream_t st) { return S->comm.exchange_halo(st, a, g, sizeof(T), S->D, g.zh); }, "halo exchange");
     }
 
     // ---- linearSolver (simulation.cpp:251-273) -----------------------------------------
@@ -453,63 +465,215 @@ struct Engine : EngineBase {
     }
     int ensure_tuned(int cur, int rhs, int b, T a, T inv_c)
     {
-        if (!two_sweep_kernels() && !fs::fused_supported<T>(S->tune, g, sc, 3)) return FS_OK;
-        const int opt = S->tune.pair_shape + 16 * S->tune.two_kind;
-        if (pair_shape >= 0 && tuned_fuse == S->tune.fuse && tuned_pair_shape_opt == opt && tuned_plan_two == S->plan_two &&
-            tuned_plan_three == S->plan_three)
-            return FS_OK;
-        tuned_fuse = S->tune.fuse;
-        tuned_pair_shape_opt = opt;
-        tuned_plan_two = S->plan_two;
-        tuned_plan_three = S->plan_three;
-        return choose_pair_shape(cur, rhs, b, a, inv_c);
+        if (two_sweep_kernels() || fs::fused_supported<T>(S->tune, g, sc, 3)) {
+            const int opt = S->tune.pair_shape + 16 * S->tune.two_kind;
+            if (!(pair_shape >= 0 && tuned_fuse == S->tune.fuse && tuned_pair_shape_opt == opt && tuned_plan_two == S->plan_two &&
+                  tuned_plan_three == S->plan_three)) {
+                tuned_fuse = S->tune.fuse;
+                tuned_pair_shape_opt = opt;
+                tuned_plan_two = S->plan_two;
+                tuned_plan_three = S->plan_three;
+                int rc = choose_pair_shape(cur, rhs, b, a, inv_c);
+                if (rc) return rc;
+            }
+        }
+        if (S->comm.active() && S->overlap_plan < 0) return choose_overlap(cur, rhs, b, a, inv_c);
+        return FS_OK;
     }
 
-    // Returns the id of the array holding the result (held); `cur` holds the initial
-    // iterate (may equal rhs when the caller aliased a snapshot).
-    // smoother = true: `sweeps` passes of two 6/7-damped Jacobi sweeps each (the level-0 smoothing step of solver=mg)
-    int solve(int b, int cur, int rhs, T a, T c, int sweeps, int* result, bool smoother = false)
+    // all ranks have finished everything queued so far (host-blocking; tuning and dumps only)
+    int slab_barrier()
     {
-        const T inv_c = (T)1 / c;                        // cRecip, :257
-        if (S->solver == FS_SOLVER_GS_LEX) {
-            if (S->comm.active()) return fail(FS_EINVAL, "gs_lex is a single-GPU verification mode");
-            if (cur == rhs) return fail(FS_EINVAL, "gs_lex needs distinct field and prev arrays");
-            ScopedSpan sp(S, FAM_SWEEP, sweeps);
-            if (sweeps > 0) fs::launch_gs_lex<T>(S->stream, g, arr[cur], arr[rhs], flags, b, a, inv_c, sweeps);
-            held[cur] = true;
-            *result = cur;
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        if (S->comm.barrier(comm_stream, red)) return fail(FS_ECOMM, "barrier: %s", S->comm.last_error());
+        return FS_OK;
+    }
+    // the largest `v` of any rank, the same bits on every rank (host-blocking; tuning only)
+    int rank_max(double v, double* out)
+    {
+        double h[3] = { v, v, v };
+        double* d3 = red + 3 * 1024;
+        HIP_TRY(hipMemcpyAsync(d3, h, sizeof h, hipMemcpyHostToDevice, S->stream));
+        int rc = comm_op([&](hipStream_t st) { return S->comm.reduce_stats(st, d3, g, S->D); }, "all-reduce");
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(h, d3, sizeof h, hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipStreamSynchronize(S->stream));
+        *out = h[2];
+        return FS_OK;
+    }
+
+    // "overlap" = "auto" (and "comm_cus" = "auto"): the communication schedules are chosen the way launch plans are -- by the
+    // clock, once, on the transport the run really uses.  Every candidate runs a chain of the solver's deepest passes with
+    // their exchanges between two barriers; what counts is the slowest rank's time (all-reduced, so that every rank takes
+    // the same decision: the schedule must not diverge).  A later candidate has to win by 1.5 %.  The bits do not depend on
+    // the choice (tests/test_gpu_slabs.py runs every candidate).
+    int choose_overlap(int src, int rhs, int b, T a, T inv_c)
+    {
+        const bool auto_cus = S->comm_cus < 0 && S->stream_masked;
+        const bool can2 = two_sweep_kernels(), can3 = triple_alt >= 0;
+        const int lv = can3 ? 3 : can2 ? 2 : 1;
+        std::vector<int> modes;
+        if (S->overlap >= 0) modes.push_back(S->overlap);
+        else if (g.D < 2 * lv + 8) modes.push_back(0);                 // too thin for a boundary/interior split: one schedule
+        else modes = { 1, 0, 2 };
+        if (modes.size() == 1 && !auto_cus) {
+            S->overlap_plan = modes[0];
+            if (S->cus_plan < 0) S->cus_plan = 0;
             return FS_OK;
         }
-        int src = cur;
-        bool src_temp = false;
-        // solver=rbsor: every iteration is one pass of the pair kernel (its two levels are the two colours)
-        const bool rb = smoother || (S->solver == FS_SOLVER_RBSOR);
-        rb_omega = smoother ? (T)6 / (T)7 : (T)S->omega;
-        rb_damped = smoother;
-        if (rb && !fs::pair_supported<T>(S->tune, g, sc))
-            return fail(FS_EINVAL, "solver=rbsor / mg needs rows of at most 1024 cells and sweep_fuse >= 2");
-        {
-            int rc = ensure_tuned(cur, rhs, b, a, inv_c);
-            if (rc) return rc;
+        const int t0 = acquire(src, rhs), t1 = acquire(src, rhs);
+        struct Release {
+            bool* held; int a, b; hipEvent_t e0 = nullptr, e1 = nullptr;
+            ~Release() { if (a >= 0) held[a] = false; if (b >= 0) held[b] = false; if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+        } rel{held, t0, t1};
+        if (t0 < 0 || t1 < 0) return fail(FS_ENOMEM, "array pool exhausted");
+        HIP_TRY(hipEventCreate(&rel.e0));
+        HIP_TRY(hipEventCreate(&rel.e1));
+        const bool tune_log = getenv("FS_TUNE_LOG") != nullptr;
+        const int NP = 6;
+        double best = 1e300;
+        int best_mode = modes[0], best_mask = 0;
+        int rc = FS_OK;
+        for (int mask = 0; mask < (auto_cus ? 2 : 1); ++mask) {
+            if (auto_cus) {
+                if ((rc = use_masked_stream(mask == 1))) return rc;
+                if ((rc = choose_pair_shape(src, rhs, b, a, inv_c))) return rc;   // launch plans for that many CUs
+            }
+            for (int mode : modes) {
+                double ms = 0.0;
+                for (int rep = 0; rep < 2; ++rep) {          // the second chain is the timed one
+                    if ((rc = slab_barrier())) return rc;
+                    HIP_TRY(hipEventRecord(rel.e0, S->stream));
+                    int from = src;
+                    for (int p = 0; p < NP; ++p) {
+                        const int to = (p & 1) ? t1 : t0;
+                        if ((rc = slab_pass(mode, lv, lv, p == 0, p + 1 == NP, false, arr[from], arr[rhs], arr[to], b, a, inv_c))) return rc;
+                        from = to;
+                    }
+                    HIP_TRY(hipEventRecord(rel.e1, S->stream));
+                    HIP_TRY(hipEventSynchronize(rel.e1));
+                    float t = 0;
+                    HIP_TRY(hipEventElapsedTime(&t, rel.e0, rel.e1));
+                    ms = (double)t / NP;
+                }
+                double worst = ms;
+                if ((rc = rank_max(ms, &worst))) return rc;
+                S->overlap_ms[3 * mask + mode] = worst;
+                if (tune_log)
+                    fprintf(stderr, "fluidsim tune: rank %d overlap=%d cu mask %s: %.4f ms per pass here, %.4f on the slowest rank\n",
+                            S->comm.rank, mode, mask ? "on" : "off", ms, worst);
+                if (worst < best * 0.985) { best = worst; best_mode = mode; best_mask = mask; }
+            }
         }
+        if (auto_cus) {
+            if ((rc = use_masked_stream(best_mask == 1))) return rc;
+            if ((rc = choose_pair_shape(src, rhs, b, a, inv_c))) return rc;
+        }
+        if (S->cus_plan < 0) S->cus_plan = 0;
+        S->overlap_plan = best_mode;
+        if (S->comm.rank == 0 && !S->quiet)
+            fprintf(stderr, "fluidsim: communication schedule overlap=%d, %d CUs kept free (timed: slowest rank %.3f ms per %d-sweep pass)\n",
+                    best_mode, S->cus_plan, best, lv);
+        return FS_OK;
+    }
+
+    // A solve in progress: the list of its passes and where it stands.  step() interleaves the (dead) density solve of
+    // a slab run with the velocity advection, so a solve can be paused between two passes.
+    struct SolveRun {
+        std::vector<int> plan;       // levels of each pass
+        int next = 0;                // first pass not yet launched
+        int b = 0, rhs = -1, src = -1;
+        bool src_temp = false, rb = false, damped = false;
+        T a = (T)0, inv_c = (T)1, omega = (T)1;
+    };
+
+    // One pass of a slab rank and the exchange of its boundary planes: `e` planes per side go to the neighbours (what their
+    // next pass needs).  `first` / `last`: first / last pass of a run of passes queued back to back (the two-stream
+    // schedule chains its events from pass to pass).
+    int slab_pass(int mode, int lv, int e, bool first, bool last, bool rb, const T* src, const T* rhs, T* dst, int b, T a, T inv_c)
+    {
+        auto exchange = [&](hipStream_t st) { return S->comm.exchange_halo(st, dst, g, sizeof(T), S->D, e); };
+        if (g.D < 2 * e + 8) mode = 0;                    // too thin to split into boundary and interior
+        const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
+        auto boundary = [&](hipStream_t st) {
+            if (!sc.lo_wall && !sc.hi_wall) launch_pass(st, lv, rb, src, rhs, dst, b, a, inv_c, 1, e, g.D - e + 1);
+            else if (!sc.lo_wall) launch_pass(st, lv, rb, src, rhs, dst, b, a, inv_c, 1, e);
+            else if (!sc.hi_wall) launch_pass(st, lv, rb, src, rhs, dst, b, a, inv_c, g.D - e + 1, g.D);
+        };
+        if (mode == 2) {
+            // Two streams: the boundary regions of pass k and its interior only depend on pass k-1, not on each other, so
+            // they are queued side by side -- boundary launch + exchange on the communication stream, interior on the
+            // compute stream.  Interior k reads the halo planes that exchange k-1 fills (a pass of lv levels reads lv
+            // planes beyond its range) and overwrites what boundary k-1 read: it waits for the event behind exchange k-1
+            // (round-2 advice: waiting for boundary k-1 alone was a race whenever a pass had more levels than the next).
+            if (first) HIP_TRY(hipEventRecord(ev_int, S->stream));                 // everything queued so far
+            else HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));               // boundary k-1 and exchange k-1
+            HIP_TRY(hipStreamWaitEvent(comm_stream, ev_int, 0));                   // boundary k reads interior k-1
+            boundary(comm_stream);
+            launch_pass(S->stream, lv, rb, src, rhs, dst, b, a, inv_c, in_lo, in_hi);
+            HIP_TRY(hipEventRecord(ev_int, S->stream));
+            if (exchange(comm_stream)) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
+            HIP_TRY(hipEventRecord(ev_halo, comm_stream));
+            if (last) HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));          // whoever reads the result next runs on the compute stream
+        } else if (mode == 1) {
+            // Boundary planes first (both regions in one launch); their exchange travels on the communication stream
+            // while the interior planes are computed; the next launch waits for it.
+            boundary(S->stream);
+            HIP_TRY(hipEventRecord(ev_edges, S->stream));
+            launch_pass(S->stream, lv, rb, src, rhs, dst, b, a, inv_c, in_lo, in_hi);
+            HIP_TRY(hipStreamWaitEvent(comm_stream, ev_edges, 0));
+            if (exchange(comm_stream)) return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
+            HIP_TRY(hipEventRecord(ev_halo, comm_stream));
+            HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
+        } else {
+            launch_pass(S->stream, lv, rb, src, rhs, dst, b, a, inv_c, 1, g.D);
+            return comm_op(exchange, "halo exchange");
+        }
+        return FS_OK;
+    }
+
+    // `cur` holds the initial iterate (may equal rhs when the caller aliased a snapshot).
+    // smoother = true: `sweeps` passes of two 6/7-damped Jacobi sweeps each (the level-0 smoothing step of solver=mg)
+    int solve_begin(SolveRun& r, int b, int cur, int rhs, T a, T c, int sweeps, bool smoother = false)
+    {
+        r = SolveRun();
+        r.b = b; r.rhs = rhs; r.src = cur; r.a = a;
+        r.inv_c = (T)1 / c;                              // cRecip, :257
+        // solver=rbsor: every iteration is one pass of the pair kernel (its two levels are the two colours)
+        r.rb = smoother || (S->solver == FS_SOLVER_RBSOR);
+        r.omega = smoother ? (T)6 / (T)7 : (T)S->omega;
+        r.damped = smoother;
+        if (r.rb && !fs::pair_supported<T>(S->tune, g, sc))
+            return fail(FS_EINVAL, "solver=rbsor / mg needs rows of at most 1024 cells and sweep_fuse >= 2");
+        int rc = ensure_tuned(cur, rhs, b, a, r.inv_c);
+        if (rc) return rc;
         // The passes of this solve: three sweeps per pass while at least three remain (where that kernel
         // exists and was found faster), then two, then one.  Under z-slabs every rank derives the same list
         // (it fixes the depth of every halo exchange).
         const bool can2 = two_sweep_kernels(), can3 = triple_alt >= 0;
-        std::vector<int> plan;
         for (int left = sweeps; left > 0;) {
-            if (rb) { plan.push_back(2); left -= 1; continue; }          // an rbsor iteration runs as a two-level pass
+            if (r.rb) { r.plan.push_back(2); left -= 1; continue; }      // an rbsor iteration runs as a two-level pass
             const int lv = (can3 && left >= 3) ? 3 : (can2 && left >= 2) ? 2 : 1;
-            plan.push_back(lv);
+            r.plan.push_back(lv);
             left -= lv;
         }
-        const int npass = (int)plan.size();
-        if (npass > 0 && S->comm.active() && (plan[0] > 1 || npass > 1)) {
+        const int npass = (int)r.plan.size();
+        if (npass > 0 && S->comm.active() && (r.plan[0] > 1 || npass > 1)) {
             // a fused pass recomputes the lower levels of the neighbours' boundary planes: it reads the
             // right-hand side there, so its halo planes must be current
-            int rc = halo(arr[rhs]);
-            if (rc) return rc;
+            if ((rc = halo(arr[rhs]))) return rc;
         }
+        return FS_OK;
+    }
+
+    // launch passes next .. upto-1
+    int solve_passes(SolveRun& r, int upto)
+    {
+        const int npass = (int)r.plan.size();
+        if (upto > npass) upto = npass;
+        if (r.next >= upto) return FS_OK;
+        rb_omega = r.omega;
+        rb_damped = r.damped;
         int span = -1, span_fam = -1;
         long span_launches = 0;
         auto close_span = [&]() {
@@ -517,9 +681,10 @@ struct Engine : EngineBase {
             span = -1;
             span_launches = 0;
         };
-        for (int i = 0; i < npass; ++i) {
-            const int lv = plan[i];
-            int dst = acquire(src, rhs);
+        const int first = r.next;
+        for (int i = first; i < upto; ++i) {
+            const int lv = r.plan[i];
+            int dst = acquire(r.src, r.rhs);
             if (dst < 0) return fail(FS_ENOMEM, "array pool exhausted");
             // one event pair around each run of equal passes (an event pair per launch costs 2 % at 512^3 and
             // 16 % at 256^3); launches are counted so that time / launches is the mean launch time.  On slabs
@@ -529,62 +694,49 @@ struct Engine : EngineBase {
             if (span < 0) { span = S->span_begin(fam); span_fam = fam; }
             ++span_launches;
             if (!S->comm.active()) {
-                launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, g.D);
+                launch_pass(S->stream, lv, r.rb, arr[r.src], arr[r.rhs], arr[dst], r.b, r.a, r.inv_c, 1, g.D);
             } else {
                 // planes a neighbour needs of this pass's result: as many as its next pass has levels; after
                 // the last pass the halos are brought to their full depth (what every other kernel assumes)
-                const int e = (i + 1 < npass) ? plan[i + 1] : g.zh;
-                if (S->overlap == 2 && g.D >= 2 * e + 8) {
-                    // Two streams: the boundary regions of pass k and its interior only depend on pass k-1, not on each
-                    // other, so they are queued side by side -- boundary launch + exchange on the high-priority
-                    // communication stream, interior on the compute stream -- and the hardware overlaps them.
-                    const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
-                    if (i > 0) HIP_TRY(hipStreamWaitEvent(S->stream, ev_edges, 0));      // interior k reads (and overwrites what) boundary k-1 (read)
-                    else HIP_TRY(hipEventRecord(ev_int, S->stream));                       // first pass: everything queued so far
-                    HIP_TRY(hipStreamWaitEvent(comm_stream, ev_int, 0));                   // boundary k reads interior k-1
-                    if (!sc.lo_wall && !sc.hi_wall) launch_pass(comm_stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e, g.D - e + 1);
-                    else if (!sc.lo_wall) launch_pass(comm_stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e);
-                    else if (!sc.hi_wall) launch_pass(comm_stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, g.D - e + 1, g.D);
-                    HIP_TRY(hipEventRecord(ev_edges, comm_stream));
-                    launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, in_lo, in_hi);
-                    HIP_TRY(hipEventRecord(ev_int, S->stream));
-                    if (S->comm.exchange_halo(comm_stream, arr[dst], g, sizeof(T), S->D, e))
-                        return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
-                    if (i + 1 == npass) {                 // whoever reads the result next runs on the compute stream
-                        HIP_TRY(hipEventRecord(ev_halo, comm_stream));
-                        HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
-                    }
-                } else if (S->overlap && g.D >= 2 * e + 8) {
-                    // Boundary planes first (both regions in one launch); their exchange then travels on
-                    // the high-priority communication stream while the interior planes are computed
-                    // (SURVEY 8e).  Measured alternatives, both slower: the boundary launch on the
-                    // communication stream beside the interior launch (overlap=2 above), and one launch whose leading
-                    // workgroups are the boundary planes with the exchange released by hipStreamWaitValue32.
-                    const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
-                    if (!sc.lo_wall && !sc.hi_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e, g.D - e + 1);
-                    else if (!sc.lo_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, e);
-                    else if (!sc.hi_wall) launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, g.D - e + 1, g.D);
-                    HIP_TRY(hipEventRecord(ev_edges, S->stream));
-                    launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, in_lo, in_hi);
-                    HIP_TRY(hipStreamWaitEvent(comm_stream, ev_edges, 0));
-                    if (S->comm.exchange_halo(comm_stream, arr[dst], g, sizeof(T), S->D, e))
-                        return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
-                    HIP_TRY(hipEventRecord(ev_halo, comm_stream));
-                    HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
-                } else {
-                    launch_pass(S->stream, lv, rb, arr[src], arr[rhs], arr[dst], b, a, inv_c, 1, g.D);
-                    if (S->comm.exchange_halo(S->stream, arr[dst], g, sizeof(T), S->D, e))
-                        return fail(FS_ECOMM, "halo exchange failed: %s", S->comm.last_error());
-                }
+                const int e = (i + 1 < npass) ? r.plan[i + 1] : g.zh;
+                int rc = slab_pass(S->overlap_plan, lv, e, i == first, i + 1 == upto, r.rb, arr[r.src], arr[r.rhs], arr[dst], r.b, r.a,
+                                   r.inv_c);
+                if (rc) { held[dst] = false; return rc; }
             }
-            if (src_temp) held[src] = false;
-            src = dst;
-            src_temp = true;
+            if (r.src_temp) held[r.src] = false;
+            r.src = dst;
+            r.src_temp = true;
         }
         close_span();
-        if (!src_temp) held[src] = true;
-        *result = src;
+        r.next = upto;
         return FS_OK;
+    }
+
+    // the id of the array holding the result (held)
+    int solve_end(SolveRun& r, int* result)
+    {
+        int rc = solve_passes(r, (int)r.plan.size());
+        if (rc) return rc;
+        if (!r.src_temp) held[r.src] = true;
+        *result = r.src;
+        return FS_OK;
+    }
+
+    int solve(int b, int cur, int rhs, T a, T c, int sweeps, int* result, bool smoother = false)
+    {
+        if (S->solver == FS_SOLVER_GS_LEX) {
+            if (S->comm.active()) return fail(FS_EINVAL, "gs_lex is a single-GPU verification mode");
+            if (cur == rhs) return fail(FS_EINVAL, "gs_lex needs distinct field and prev arrays");
+            ScopedSpan sp(S, FAM_SWEEP, sweeps);
+            if (sweeps > 0) fs::launch_gs_lex<T>(S->stream, g, arr[cur], arr[rhs], flags, b, a, (T)1 / c, sweeps);
+            held[cur] = true;
+            *result = cur;
+            return FS_OK;
+        }
+        SolveRun r;
+        int rc = solve_begin(r, b, cur, rhs, a, c, sweeps, smoother);
+        if (rc) return rc;
+        return solve_end(r, result);
     }
 
     // Times the candidate launch plans of the two-sweep kernels on this grid -- the pair kernel's workgroup
@@ -719,6 +871,7 @@ struct Engine : EngineBase {
 
     int linear_solver(int b, int field, int prev, float a, float c) override
     {
+        if (!in_step) vzmax_prev = -1.0;             // a call from outside step(): what is known about v_z is void
         int rc = ensure_flags();
         if (rc) return rc;
         if (S->solver == FS_SOLVER_GS_LEX && (rc = unalias(field))) return rc;
@@ -747,10 +900,11 @@ struct Engine : EngineBase {
         adopt(field, res);
         return FS_OK;
     }
-    int diffuse(int b, int field, int prev) override { return diffuse_T(b, field, prev); }
+    int diffuse(int b, int field, int prev) override { if (!in_step) vzmax_prev = -1.0; return diffuse_T(b, field, prev); }
 
     int set_bounds(int b, int field) override
     {
+        if (!in_step) vzmax_prev = -1.0;             // a call from outside step(): what is known about v_z is void
         int rc = ensure_flags();
         if (rc) return rc;
         if ((rc = unalias(field))) return rc;
@@ -808,6 +962,7 @@ struct Engine : EngineBase {
     // ---- project (simulation.cpp:289-362) ----------------------------------------------
     int project() override
     {
+        if (!in_step) vzmax_prev = -1.0;             // a call from outside step(): what is known about v_z is void
         int rc = ensure_flags();
         if (rc) return rc;
         for (int f : { FS_VX, FS_VY, FS_VZ, FS_PRESSURE, FS_DIVERGENCE })
@@ -836,12 +991,62 @@ struct Engine : EngineBase {
         // (v_z[z+-1]) and the advection back-trace; refresh them now.
         for (int f : { FS_VX, FS_VY, FS_VZ })
             if ((rc = halo(arr[slot[f]]))) return rc;
+        if (in_step && S->comm.active() && (rc = post_vzmax(projections_this_step++))) return rc;
         return FS_OK;
+    }
+
+    // ---- reach of the back-trace on a slab, without stalling the device ----------------------------------------
+    // Inside step() the z velocity that carries each advection is known: after the first projection for v_x / v_y,
+    // v_z_prev (= the end of the previous step) for v_z, after the second projection for the density.  Its global
+    // max |.| is queued right behind the projection -- device reduction, all-reduce, copy into pinned memory, an event
+    // -- and step() puts half of the density solve (independent work) between that and the gather that needs it.
+    int projections_this_step = 0;
+    int post_vzmax(int which)
+    {
+        if (which < 0 || which > 2) return FS_OK;
+        ScopedSpan sp(S, FAM_COMM);
+        double* out3 = red + 3 * 1024 + 3 * (2 + which);
+        const int zlo = sc.lo_wall ? 0 : 1, zhi = sc.hi_wall ? g.D + 1 : g.D;
+        fs::launch_stats<T>(S->stream, g, arr[slot[FS_VZ]], out3, red, 3 * 1024, zlo, zhi);
+        int rc = comm_op([&](hipStream_t st) { return S->comm.reduce_stats(st, out3, g, S->D); }, "all-reduce of max |v_z|");
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(reach_pinned + 3 * which, out3, 3 * sizeof(double), hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipEventRecord(ev_reach[which], S->stream));
+        reach_posted[which] = true;
+        return FS_OK;
+    }
+    // max |v_z| posted by post_vzmax(which); false if nothing was posted (caller falls back to trace_reach)
+    bool take_vzmax(int which, double* umax)
+    {
+        if (!reach_posted[which]) return false;
+        ++S->n_reach_waits;
+        if (hipEventQuery(ev_reach[which]) != hipSuccess) {
+            ++S->n_reach_blocked;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (hipEventSynchronize(ev_reach[which]) != hipSuccess) return false;
+            S->reach_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        const double* st = reach_pinned + 3 * which;
+        *umax = std::fmax(std::fabs(st[1]), std::fabs(st[2]));
+        return true;
+    }
+    // max |v_z_prev| of the running step: carried over from the previous step, or posted at the start of this one
+    bool prev_vzmax_known(double* umax)
+    {
+        if (vzmax_prev < 0.0 && !take_vzmax(2, &vzmax_prev)) return false;
+        *umax = vzmax_prev;
+        return true;
+    }
+    int reach_of(double umax) const
+    {
+        const double planes = std::ceil(std::fabs((double)S->dt * (double)S->D) * umax) + 2.0;
+        return planes >= (double)S->D ? S->D : (int)planes;
     }
 
     // ---- advect (simulation.cpp:367-424) ------------------------------------------------
     int advect(int b, int field, int prev) override
     {
+        if (!in_step) vzmax_prev = -1.0;             // a call from outside step(): what is known about v_z is void
         int rc = ensure_flags();
         if (rc) return rc;
         if (slot[field] == slot[prev]) {
@@ -862,8 +1067,14 @@ struct Engine : EngineBase {
             // within that reach of the slab are fetched from their owners.
             ScopedSpan sp(S, FAM_COMM);
             int reach = 0;
-            if ((rc = trace_reach({ b == 3 ? prev : FS_VZ }, &reach))) return rc;
-            if ((rc = gather_source(src, &gathered, reach))) return rc;
+            double umax = -1.0;
+            // inside step(): v_x / v_y are carried by v_z after the first projection, the density by v_z after the second,
+            // v_z by v_z_prev (the end of the previous step, where known)
+            const bool known = in_step && (b == 3 ? prev_vzmax_known(&umax) : take_vzmax(b == 0 ? 1 : 0, &umax));
+            if (known && b == 0) vzmax_end = umax;       // v_z does not change any more in this step: next step's v_z_prev
+            if (known) S->last_reach = reach = reach_of(umax);
+            else if ((rc = trace_reach({ b == 3 ? prev : FS_VZ }, &reach))) return rc;
+            if ((rc = gather_source(src, &gathered, reach, 0))) return rc;
             src = gathered;
             zshift = (long)sc.zoff * g.sz;
         }
@@ -888,21 +1099,24 @@ struct Engine : EngineBase {
             double* out3 = red + 3 * 1024 + 3 * k;
             const int zlo = sc.lo_wall ? 0 : 1, zhi = sc.hi_wall ? g.D + 1 : g.D;
             fs::launch_stats<T>(S->stream, g, arr[slot[f]], out3, red, 3 * 1024, zlo, zhi);
-            if (S->comm.active() && S->comm.reduce_stats(S->stream, out3, g, S->D))
-                return fail(FS_ECOMM, "stats all-reduce failed: %s", S->comm.last_error());
+            if (S->comm.active()) {
+                int rc = comm_op([&](hipStream_t cs) { return S->comm.reduce_stats(cs, out3, g, S->D); }, "stats all-reduce");
+                if (rc) return rc;
+            }
             ++k;
         }
         HIP_TRY(hipMemcpyAsync(&st[0][0], red + 3 * 1024, 3 * k * sizeof(double), hipMemcpyDeviceToHost, S->stream));
         HIP_TRY(hipStreamSynchronize(S->stream));
+        ++S->n_stream_syncs;
         double umax = 0.0;
         for (int i = 0; i < k; ++i) umax = std::fmax(umax, std::fmax(std::fabs(st[i][1]), std::fabs(st[i][2])));
-        const double planes = std::ceil(std::fabs((double)S->dt * (double)S->D) * umax) + 2.0;
-        *reach = planes >= (double)S->D ? S->D : (int)planes;
+        *reach = reach_of(umax);
         S->last_reach = *reach;
         return FS_OK;
     }
 
-    int gather_source(const T* src, T** buf, int reach)
+    // `which`: 0 = `gathered`, 1..3 = `gathered3` (the FSIPC export slot of the buffer)
+    int gather_source(const T* src, T** buf, int reach, int which)
     {
         const long n = g.sz * ((long)S->D + 2) + 8;
         if (!*buf) {
@@ -910,12 +1124,16 @@ struct Engine : EngineBase {
             HIP_TRY(hipMalloc((void**)&base, n * sizeof(T)));
             HIP_TRY(hipMemsetAsync(base, 0, n * sizeof(T), S->stream));
             *buf = base + fs::LEAD;
+            // every rank allocates it at the same point of the step: a collective export (FSIPC; the owners write into it)
+            if (S->comm.register_buffer(SLOT_GATHER + which, base, (size_t)n * sizeof(T), true))
+                return fail(FS_ECOMM, "exporting the gathered advection source: %s", S->comm.last_error());
         }
         if (S->debug_poison) HIP_TRY(hipMemsetAsync(*buf - fs::LEAD, 0xFF, n * sizeof(T), S->stream));
-        int rc = (reach >= S->D) ? S->comm.all_gather_planes(S->stream, src, *buf, g, S->D, sizeof(T))
-                                 : S->comm.gather_window(S->stream, src, *buf, g, S->D, sizeof(T), reach);
-        if (rc) return fail(FS_ECOMM, "gather of the advection source failed: %s", S->comm.last_error());
-        return FS_OK;
+        T* dst = *buf;
+        return comm_op([&](hipStream_t st) {
+            return (reach >= S->D) ? S->comm.all_gather_planes(st, src, dst, g, S->D, sizeof(T))
+                                   : S->comm.gather_window(st, src, dst, g, S->D, sizeof(T), reach); },
+                       "gather of the advection source");
     }
 
     // advect(1,v_x,v_x_prev); advect(2,v_y,v_y_prev); advect(3,v_z,v_z_prev) in one kernel
@@ -930,9 +1148,12 @@ struct Engine : EngineBase {
             // the z velocity carrying the three traces is the current v_z (x, y) or v_z_prev (z)
             ScopedSpan sp(S, FAM_COMM);
             int reach = 0;
-            if ((rc = trace_reach({ FS_VZ, FS_VZ_PREV }, &reach))) return rc;
+            double umax = -1.0;
+            double uprev = -1.0;
+            if (in_step && prev_vzmax_known(&uprev) && take_vzmax(0, &umax)) S->last_reach = reach = reach_of(std::fmax(umax, uprev));
+            else if ((rc = trace_reach({ FS_VZ, FS_VZ_PREV }, &reach))) return rc;
             for (int k = 0; k < 3; ++k) {
-                if ((rc = gather_source(p[k], &gathered3[k], reach))) return rc;
+                if ((rc = gather_source(p[k], &gathered3[k], reach, 1 + k))) return rc;
                 p[k] = gathered3[k];
             }
             zshift = (long)sc.zoff * g.sz;
@@ -950,6 +1171,11 @@ struct Engine : EngineBase {
     // ---- step (simulation.cpp:96-150) ---------------------------------------------------
     int step() override
     {
+        struct InStep {                                  // the reach bookkeeping of this step; cleared on every exit
+            Engine* e;
+            explicit InStep(Engine* e_) : e(e_) { e->in_step = true; e->projections_this_step = 0; e->reach_posted[0] = e->reach_posted[1] = e->reach_posted[2] = false; e->vzmax_end = -1.0; }
+            ~InStep() { e->in_step = false; e->vzmax_prev = e->vzmax_end; }
+        } scope(this);
         int rc = ensure_flags();
         if (rc) return rc;
         const bool gs = (S->solver == FS_SOLVER_GS_LEX);
@@ -960,6 +1186,9 @@ struct Engine : EngineBase {
             fs::launch_inlet_velocity<T>(S->stream, g, sc, arr[slot[FS_VX]], arr[slot[FS_VY]], arr[slot[FS_VZ]],
                                          (T)(float)S->speed);   // :103-105
         }
+        // z-slabs: v_z as it is now becomes v_z_prev, which carries the advection of v_z; where its max |.| is not known from
+        // the previous step (first step, host-side edits) it is queued here and has the whole diffusion to arrive
+        if (S->comm.active() && vzmax_prev < 0.0 && (rc = post_vzmax(2))) return rc;
         // :108-110  v_*_prev = v_*  (pre-diffusion snapshot).  Jacobi never writes its input, so
         // the snapshot is an alias and the copy costs nothing; the in-place mode really copies.
         const int V[3] = { FS_VX, FS_VY, FS_VZ }, V0[3] = { FS_VX_PREV, FS_VY_PREV, FS_VZ_PREV };
@@ -975,6 +1204,17 @@ struct Engine : EngineBase {
         for (int k = 0; k < 3; ++k)                      // :115-117
             if ((rc = diffuse_T(k + 1, V[k], V0[k]))) return rc;
         if ((rc = project())) return rc;                 // :120
+        // z-slabs: :135's density solve (independent of the velocities; its result is dead, :136 overwrites it) is the work
+        // the device does while the reach of each advection travels to the host -- half of its passes here, between the
+        // first projection and the velocity advection, the other half where the reference has it, between the second
+        // projection and the density advection.  Same passes, same order, same bits.
+        const bool split = S->comm.active() && S->split_dens && !S->elide_dead && !gs && S->acc > 0;
+        SolveRun dens_run;
+        if (split) {
+            const T a = diffusion_a();
+            if ((rc = solve_begin(dens_run, 0, slot[FS_DENS], slot[FS_BUFFER], a, (T)1 + (T)6 * a, S->acc))) return rc;   // :283
+            if ((rc = solve_passes(dens_run, (int)dens_run.plan.size() / 2))) return rc;
+        }
         if (S->fuse_advect && slot[FS_VX] != slot[FS_VX_PREV] && slot[FS_VY] != slot[FS_VY_PREV] &&
             slot[FS_VZ] != slot[FS_VZ_PREV]) {
             // :125-127 in one pass (the three traces only chain through the cell's own values)
@@ -984,7 +1224,11 @@ struct Engine : EngineBase {
                 if ((rc = advect(k + 1, V[k], V0[k]))) return rc;
         }
         if ((rc = project())) return rc;                 // :130
-        if (!S->elide_dead) {                            // :135 (its result is overwritten by :136)
+        if (split) {
+            int res;
+            if ((rc = solve_end(dens_run, &res))) return rc;
+            adopt(FS_DENS, res);
+        } else if (!S->elide_dead) {                     // :135 (its result is overwritten by :136)
             if ((rc = diffuse_T(0, FS_DENS, FS_BUFFER))) return rc;
         }
         if ((rc = advect(0, FS_DENS, FS_BUFFER))) return rc;   // :136
@@ -1034,6 +1278,7 @@ struct Engine : EngineBase {
 
     int set_field(int which, const void* src, size_t n, int elem) override
     {
+        if (!in_step) vzmax_prev = -1.0;             // a call from outside step(): what is known about v_z is void
         if ((long)n != dense_cells()) return fail(FS_EINVAL, "set_field: expected %ld elements, got %zu", dense_cells(), n);
         if (elem != 4 && elem != 8 && elem != 1) return fail(FS_EINVAL, "elem_size must be 1, 4 or 8");
         // a slot that shares its array gets a fresh one; contents are fully overwritten below
@@ -1061,6 +1306,7 @@ struct Engine : EngineBase {
 
     int point(int which, int x, int y, int z, float v, int set_instead) override
     {
+        if (!in_step) vzmax_prev = -1.0;             // a call from outside step(): what is known about v_z is void
         // x,y are global = local; z is global and must fall into this slab to have an effect.
         // The bookkeeping is the same on EVERY rank (every rank issues the same call): the slot maps
         // must not diverge, and ensure_halos() / ensure_flags() are collectives gated on these bits --
@@ -1276,8 +1522,10 @@ struct Engine : EngineBase {
         // the physical ghost planes it holds, and the partial results are all-reduced
         const int zlo = sc.lo_wall ? 0 : 1, zhi = sc.hi_wall ? g.D + 1 : g.D;
         fs::launch_stats<T>(S->stream, g, field, red + 3 * 1024, red, 3 * 1024, zlo, zhi);
-        if (S->comm.active() && S->comm.reduce_stats(S->stream, red + 3 * 1024, g, S->D))
-            return fail(FS_ECOMM, "stats all-reduce failed: %s", S->comm.last_error());
+        if (S->comm.active()) {
+            int rc = comm_op([&](hipStream_t cs) { return S->comm.reduce_stats(cs, red + 3 * 1024, g, S->D); }, "stats all-reduce");
+            if (rc) return rc;
+        }
         HIP_TRY(hipMemcpyAsync(out3, red + 3 * 1024, 3 * sizeof(double), hipMemcpyDeviceToHost, S->stream));
         HIP_TRY(hipStreamSynchronize(S->stream));
         return FS_OK;
@@ -1303,7 +1551,7 @@ struct Engine : EngineBase {
                 }
                 if (pass == 0 && S->comm.active()) {
                     if (S->comm.shm && S->comm.shm_ready(g, S->D)) return fail(FS_ECOMM, "%s", S->comm.last_error());
-                    if (S->comm.barrier(S->stream, red)) return fail(FS_ECOMM, "dump barrier: %s", S->comm.last_error());
+                    { int brc = slab_barrier(); if (brc) return brc; }
                 }
             }
             if (!ok) {
@@ -1455,9 +1703,16 @@ int fs_destroy(fs_sim* s)
     }
     for (int k = 0; k < 5; ++k)
         if (s->dump_fp[k]) fclose(s->dump_fp[k]);
+    if (s->comm.active()) hipDeviceSynchronize();   // the communication stream too
+    s->comm.release_buffers();       // FSIPC: collective; no peer maps (or still writes) this rank's arrays once it returns
     delete s->eng;
     s->comm.destroy();
-    if (s->stream) hipStreamDestroy(s->stream);
+    if (s->stream_full || s->stream_masked) {
+        if (s->stream_full) hipStreamDestroy(s->stream_full);
+        if (s->stream_masked) hipStreamDestroy(s->stream_masked);
+    } else if (s->stream) {
+        hipStreamDestroy(s->stream);
+    }
     delete s;
     return FS_OK;
 }
@@ -1508,8 +1763,16 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
     } else if (k == "fuse_advect") {
         s->fuse_advect = (v != "0");
     } else if (k == "overlap") {
-        s->overlap = atoi(value);
-        if (s->overlap < 0 || s->overlap > 2) return fail(FS_EINVAL, "overlap: 0 | 1 | 2");
+        if (s->eng && s->overlap_plan >= 0) return fail(FS_EINVAL, "overlap must be set before the first solve");
+        s->overlap = (v == "auto") ? -1 : atoi(value);
+        if (s->overlap < -1 || s->overlap > 2 || (v != "auto" && v != "0" && v != "1" && v != "2"))
+            return fail(FS_EINVAL, "overlap: auto | 0 | 1 | 2");
+    } else if (k == "comm_cus") {
+        if (s->eng) return fail(FS_EINVAL, "comm_cus must be set before first use");
+        s->comm_cus = (v == "auto") ? -1 : atoi(value);
+        if (s->comm_cus < -1 || s->comm_cus > 128) return fail(FS_EINVAL, "comm_cus: auto | 0 .. 128");
+    } else if (k == "split_density_solve") {
+        s->split_dens = (v != "0");
     } else if (k == "debug_poison_gather") {
         s->debug_poison = (v != "0");
     } else if (k == "sweep_ry") {
@@ -1569,6 +1832,13 @@ int fs_get_int(fs_sim* s, const char* name, int* out)
     else if (n == "two_sweep_fused") *out = (s->eng && s->eng->tuned_shape() >= 64) ? 1 : 0;   // 1: jacobi_fused_kernel<NL=2>, 0: jacobi_pair_kernel
     else if (n == "halo_depth") *out = s->eng ? s->eng->halo_depth() : 0;
     else if (n == "mg_levels") *out = s->eng ? s->eng->multigrid_levels() : 0;          // levels of the last solver=mg solve, level 0 included
+    // z-slab runs: the communication schedule in force (what "auto" chose), and the slab step's host-side waits
+    else if (n == "overlap_plan") *out = s->overlap_plan;
+    else if (n == "comm_cus_plan") *out = s->cus_plan;
+    else if (n == "stream_syncs") *out = (int)s->n_stream_syncs;          // hipStreamSynchronize calls issued by slab steps (reach fallback)
+    else if (n == "reach_waits") *out = (int)s->n_reach_waits;            // waits for an asynchronously delivered reach ...
+    else if (n == "reach_waits_blocked") *out = (int)s->n_reach_blocked;  // ... that found it not yet delivered
+    else if (n == "reach_wait_us") *out = (int)(s->reach_wait_ms * 1e3);  // host time spent blocked in them
     else return fail(FS_EINVAL, "unknown int member '%s'", name);
     return FS_OK;
 }
@@ -1587,6 +1857,8 @@ int fs_get_float(fs_sim* s, const char* name, float* out)
     if (!s || !name || !out) return fail(FS_EINVAL, "null argument");
     std::string n = name;
     if (n == "dt") *out = s->dt; else if (n == "diff") *out = s->diff; else if (n == "visc") *out = s->visc;
+    else if (n.size() == 11 && n.compare(0, 7, "overlap") == 0 && n.compare(8, 3, "_ms") == 0 && n[7] >= '0' && n[7] <= '5')
+        *out = (float)s->overlap_ms[n[7] - '0'];   // "overlap<k>_ms": slowest rank's ms per pass of candidate k = overlap mode + 3 * (CU mask on), 0 = not timed
     else return fail(FS_EINVAL, "unknown float member '%s'", name);
     return FS_OK;
 }
@@ -1663,6 +1935,7 @@ int fs_sync(fs_sim* s)
     HIP_TRY(hipStreamSynchronize(s->stream));
     std::string werr;
     if (s->writer.flush(&werr)) return fail(FS_EIO, "frame writer: %s", werr.c_str());
+    if (s->comm.check()) return fail(FS_ECOMM, "%s", s->comm.last_error());
     return FS_OK;
 }
 

@@ -94,3 +94,22 @@ def exchange_halo_planes(dist, field, rank, nranks, depth=1, zh=1):
     if hi is not None:
         field[at(n + 1):at(n + depth) + 1].copy_(hi)
     return field
+
+
+OVERLAP_CANDIDATES = (1, 0, 2)   # the order Engine::choose_overlap times them in (csrc/fluidsim.cpp)
+
+
+def choose_overlap_plan(dist, local_ms, device=None, hysteresis=0.985):
+    """The rule by which z-slab ranks agree on a communication schedule ("overlap" = "auto",
+    Engine::choose_overlap): every candidate's time is the SLOWEST rank's (all-reduce max), candidates are
+    compared in a fixed order and a later one has to beat the best so far by 1.5 %.  `local_ms` maps
+    candidate -> this rank's milliseconds per pass.  Every rank returns the same (plan, times)."""
+    import torch
+    t = torch.tensor([float(local_ms[c]) for c in OVERLAP_CANDIDATES], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    worst = [float(v) for v in t.cpu()]
+    best, plan = float("inf"), OVERLAP_CANDIDATES[0]
+    for c, ms in zip(OVERLAP_CANDIDATES, worst):
+        if ms < best * hysteresis:
+            best, plan = ms, c
+    return plan, dict(zip(OVERLAP_CANDIDATES, worst))

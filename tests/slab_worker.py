@@ -41,6 +41,9 @@ def main():
     if stl:
         F.loadSTLIntoObstacles(stl, sim, 0.5, 0.0, 20.0, 0.0, 3.0, 0.0, 0.0)
     sim.run()
+    # what the slab steps of that run cost the host: stream synchronisations (none: the reach of every back-trace arrives
+    # asynchronously), waits for a reach, those that found it not yet delivered; and the communication schedule in force
+    sched = np.array([sim._geti(k) for k in ("stream_syncs", "reach_waits", "reach_waits_blocked", "overlap_plan", "comm_cus_plan")])
     # host-side edits on and next to slab boundaries (every rank issues the same calls; a rank applies
     # those that fall into its planes), then two more steps: the stale-halo bookkeeping must catch them
     for zb in sorted({D // 2, D // 2 + 1, max(1, D // 4), min(D, 3 * D // 4 + 1)}):
@@ -67,7 +70,9 @@ def main():
     stats = np.array(sim.stats(F.DENS) + sim.stats(F.VX))
     reach = sim._geti("last_advect_reach")
     kernels = np.array([sim._geti("triple_plan"), sim._geti("two_sweep_fused"), sim._geti("halo_depth")])
-    np.savez(os.path.join(outdir, "rank%d.npz" % rank), zoff=zoff, stats=stats, reach=reach, kernels=kernels, **out)
+    sched_end = np.array([sim._geti(k) for k in ("stream_syncs", "reach_waits", "reach_waits_blocked")])
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), zoff=zoff, stats=stats, reach=reach, kernels=kernels, sched=sched,
+             sched_end=sched_end, **out)
     sim.close()
 
 

@@ -28,6 +28,21 @@ uid = D.share_unique_id(dist, lambda: bytes(range(128)), rank)
 assert uid == bytes(range(128))
 assert D.max_over_ranks(dist, 1.0 + rank) == float(world)
 
+# "overlap" = "auto": the ranks' own clocks disagree (each would pick another schedule), the agreed plan does not
+local = {0: 1.00 + 0.30 * rank, 1: 1.20 - 0.25 * rank, 2: 1.10 + (0.2 if rank == world - 1 else -0.3)}
+mine = min(local, key=local.get)
+plan, worst = D.choose_overlap_plan(dist, local)
+plans = [None] * world
+dist.all_gather_object(plans, (plan, sorted(worst.items()), mine))
+assert len({(p, tuple(w)) for p, w, _ in plans}) == 1, plans            # one plan, one set of times, on every rank
+assert len({m for _, _, m in plans}) > 1, plans                         # although the local favourites differ
+for c in D.OVERLAP_CANDIDATES:
+    assert worst[c] == max(({0: 1.00 + 0.30 * r, 1: 1.20 - 0.25 * r, 2: 1.10 + (0.2 if r == world - 1 else -0.3)})[c] for r in range(world))
+# hysteresis: a later candidate within 1.5 %% of the best so far does not displace it
+same = D.choose_overlap_plan(dist, {1: 1.000, 0: 0.990, 2: 0.991})[0]
+assert same == 1, same
+assert D.choose_overlap_plan(dist, {1: 1.000, 0: 0.980, 2: 0.979})[0] == 0
+
 # single-domain truth from the oracle (every rank computes it; tiny)
 rng = np.random.default_rng(3)
 x = rng.standard_normal((Dz + 2, H + 2, W + 2)).astype(np.float32)

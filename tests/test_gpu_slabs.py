@@ -16,30 +16,70 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(ROOT, "tests", "slab_worker.py")
 
 
-def run_ranks(tmp, nranks, args, env=None):
+_REF_RUNS = {}          # single-GPU runs, shared by the cases that compare against the same one
+_IPC = {}
+
+
+def ipc_usable():
+    """The FSIPC transport needs hipIpc memory handles between processes that share the GPU; where the pool refuses
+    them the cases over it are skipped, with the probe's own words as the reason (tools/ipc_probe.cpp)."""
+    if "ok" not in _IPC:
+        exe = os.path.join(ROOT, "tools", "ipc_probe")
+        if not os.path.exists(exe):
+            _IPC["ok"], _IPC["why"] = False, "tools/ipc_probe was not built (python -c 'import __graft_entry__ as g; g.build()')"
+        else:
+            r = subprocess.run([exe, "2", "8", "1"], capture_output=True, text=True, timeout=120,
+                               env=dict(os.environ, FS_IPC_TIMEOUT_S="20"))
+            _IPC["ok"], _IPC["why"] = r.returncode == 0, (r.stdout + r.stderr)[-400:]
+    return _IPC["ok"], _IPC["why"]
+
+
+def run_ranks(tmp, nranks, args, env=None, transport="shm"):
+    key = (tuple(str(a) for a in args), tuple(sorted((env or {}).items())))
+    if nranks == 1 and key in _REF_RUNS:
+        return _REF_RUNS[key]
     out = os.path.join(tmp, "n%d" % nranks)
     os.makedirs(os.path.join(out, "data"))
     idfile = os.path.join(out, "id.bin")
     if nranks > 1:
         import fluid_simulation_amd as F
-        open(idfile, "wb").write(F.comm_unique_id("shm"))
+        open(idfile, "wb").write(F.comm_unique_id(transport))
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(nranks), idfile, out] + [str(a) for a in args],
-                              env=dict(os.environ, **(env or {}))) for r in range(nranks)]
+                              env=dict(os.environ, FS_IPC_TIMEOUT_S="60", **(env or {}))) for r in range(nranks)]
     for p in procs:
         assert p.wait(timeout=600) == 0
+    if nranks == 1:
+        _REF_RUNS[key] = out
     return out
 
 
-@pytest.mark.parametrize("nranks,D,opts", [(2, 16, ""), (4, 16, ""), (2, 32, ""), (3, 48, ""), (2, 32, "overlap=0"),
-                                            (2, 32, "overlap=2"), (3, 48, "overlap=2")])
-def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D, opts):
-    # local depth 16 (D=32 and D=48 cases) is deep enough for the boundary-first schedule that overlaps the
-    # halo exchange with interior compute (overlap=1, the default; overlap=2 queues the boundary launch and the
-    # exchange on the communication stream beside the interior launch); depth 8 and 4 take the plain path
-    W, H, acc, steps = 20, 12, 5, 3
-    args = [W, H, D, acc, steps, os.path.join(GOLDEN, "sphere_24x12.stl"), "fp32", "jacobi", opts]
-    ref_dir = run_ranks(str(tmp_path), 1, args)
-    par_dir = run_ranks(str(tmp_path), nranks, args)
+SCHEDULES = [
+    # (ranks, depth, options of the slab run, transport, solver iterations)
+    (2, 16, "", "shm", 5), (4, 16, "", "shm", 5), (2, 32, "", "shm", 5), (3, 48, "", "shm", 5),
+    (2, 32, "overlap=0", "shm", 5), (2, 32, "overlap=1", "shm", 7), (2, 32, "overlap=2", "shm", 7), (3, 48, "overlap=2", "shm", 8),
+    # the same over the asynchronous device-to-device transport: nothing below host-synchronises, so a missing
+    # stream dependency shows (7 and 8 iterations plan [3, 3, 1] and [3, 3, 2]: passes with more levels than the next)
+    (2, 32, "", "ipc", 5), (2, 32, "overlap=0", "ipc", 7), (2, 32, "overlap=1", "ipc", 7), (2, 32, "overlap=2", "ipc", 7),
+    (3, 48, "overlap=2", "ipc", 8), (4, 64, "", "ipc", 8), (3, 48, "comm_cus=auto", "ipc", 7), (2, 32, "comm_cus=8,overlap=1", "ipc", 5),
+    (2, 32, "split_density_solve=0", "ipc", 5), (4, 16, "", "ipc", 5),
+]
+
+
+@pytest.mark.parametrize("nranks,D,opts,transport,acc", SCHEDULES)
+def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D, opts, transport, acc):
+    """Every communication schedule (overlap = 0 / 1 / 2 and "auto", with and without CUs kept free, with and without the
+    split density solve) over both development transports: local depth 16 (D = 32, 48, 64) is deep enough for the
+    boundary-first schedules, depth 8 and 4 take the plain path.  The options only reach the slab run: the single-GPU run
+    it is compared with is the same for every schedule."""
+    if transport == "ipc":
+        ok, why = ipc_usable()
+        if not ok:
+            pytest.skip("FSIPC transport not usable on this box: " + why)
+    W, H, steps = 20, 12, 3
+    stl = os.path.join(GOLDEN, "sphere_24x12.stl")
+    args = [W, H, D, acc, steps, stl, "fp32", "jacobi", opts]
+    ref_dir = run_ranks(str(tmp_path), 1, [W, H, D, acc, steps, stl, "fp32", "jacobi", ""])
+    par_dir = run_ranks(str(tmp_path), nranks, args, transport=transport)
     ref = np.load(os.path.join(ref_dir, "rank0.npz"))
     Dl = D // nranks
     for r in range(nranks):
@@ -58,6 +98,18 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D, opts):
         assert 2 <= int(z["reach"]) < D
         # sum/min/max are all-reduced: every rank reports the global values (sum up to rounding order)
         assert np.allclose(z["stats"], ref["stats"], rtol=1e-12, atol=1e-12)
+        # the slab steps never synchronised the compute stream: every reach came through the asynchronous path, two per
+        # step (+ the one posted at the start of a step whose v_z_prev is not known from the step before) -- also across
+        # the host-side edits that make v_z jump (setVelocity with v_z = 2.0 between steps)
+        syncs, waits, blocked, plan, cus = (int(v) for v in z["sched"])
+        assert syncs == 0 and waits == 2 * steps + 1 and 0 <= blocked <= waits, (r, z["sched"])
+        assert int(z["sched_end"][0]) == 0, (r, z["sched_end"])
+        want_plan = {"overlap=0": 0, "overlap=1": 1, "overlap=2": 2}
+        forced = [v for k, v in want_plan.items() if k in opts]
+        assert plan in (0, 1, 2) and (not forced or plan == forced[0]), (r, plan)
+        assert cus == (8 if "comm_cus=8" in opts else cus) and cus in (0, 8)
+        plans = plans + [(plan, cus)] if r else [(plan, cus)]
+    assert len(set(plans)) == 1, plans                      # "auto": every rank took the same decision
     # frame dumps: ranks wrote their planes at their own offsets of the same five files
     for fn in ("data", "obs", "v_x", "v_y", "v_z"):
         a = np.fromfile(os.path.join(ref_dir, "data", fn + ".bin"), dtype=np.uint8)
