@@ -401,6 +401,9 @@ def main():
                                 "solver's own exchanges fall inside the sweep families",
             "stream_syncs": sim._geti("stream_syncs"), "reach_waits": sim._geti("reach_waits"),
             "reach_waits_blocked": sim._geti("reach_waits_blocked"), "reach_wait_us": sim._geti("reach_wait_us"),
+            "reach_hidden": sim._geti("reach_hidden"), "reach_exposed": sim._geti("reach_exposed"),
+            "reach_note": "the reach of each advection gather arrives asynchronously (no stream synchronisation); hidden / exposed = "
+                          "advections queued while the device was still busy with the half density solve placed before them / after it ran dry",
         },
         "step_bytes_per_cell_algorithmic": 208 + 72 * acc,
         "step_roofline_frac": (208 + 72 * acc) * (elem // 4) * cells * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,

@@ -115,6 +115,8 @@ struct fs_sim {
     // slab-step bookkeeping readable through fs_get_int
     long n_stream_syncs = 0;     // host synchronisations of the compute stream issued by the slab step (reach fallback path)
     long n_reach_waits = 0, n_reach_blocked = 0;   // waits for an asynchronously delivered reach; those that found it not yet there
+    long n_reach_hidden = 0, n_reach_exposed = 0;  // gathers + advections queued while the device was still busy with the half density
+                                                   // solve placed before them (hidden) / after it had run dry (exposed: a bubble)
     double reach_wait_ms = 0.0;  // host time spent in them
     int overlap_plan = -1, cus_plan = -1;          // what "auto" chose (or the forced values), -1 before the first slab solve
     double overlap_ms[6] = {0, 0, 0, 0, 0, 0};     // slowest rank's ms per pass of each timed candidate (overlap 0/1/2 x cu mask off/on)
@@ -235,6 +237,7 @@ struct Engine : EngineBase {
     // when it sizes the gather, by which time the device has long passed it (see step()).
     double* reach_pinned = nullptr;     // 3 x {sum, min, max}: after the first / second projection, at the start of the step
     hipEvent_t ev_reach[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_slack = nullptr;      // behind the independent work queued between a projection and the advection that needs its reach
     bool reach_posted[3] = {false, false, false};
     double vzmax_prev = -1.0;           // max |v_z| at the end of the previous step (= v_z_prev of this one), -1 = unknown
     double vzmax_end = -1.0;            // the same for the step that is running
@@ -295,7 +298,7 @@ struct Engine : EngineBase {
             int lo_pri = 0, hi_pri = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
             HIP_TRY(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, hi_pri));
-            for (hipEvent_t* ev : { &ev_edges, &ev_halo, &ev_int, &ev_c2x, &ev_reach[0], &ev_reach[1], &ev_reach[2] })
+            for (hipEvent_t* ev : { &ev_edges, &ev_halo, &ev_int, &ev_c2x, &ev_reach[0], &ev_reach[1], &ev_reach[2], &ev_slack })
                 HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
             HIP_TRY(hipHostMalloc((void**)&reach_pinned, 9 * sizeof(double), hipHostMallocDefault));
             // FSIPC: the neighbours write straight into these arrays
@@ -349,7 +352,7 @@ struct Engine : EngineBase {
         if (red) hipFree(red);
         if (coltab) hipFree(coltab);
         mg.release();
-        for (hipEvent_t ev : { ev_edges, ev_halo, ev_int, ev_c2x, ev_reach[0], ev_reach[1], ev_reach[2] })
+        for (hipEvent_t ev : { ev_edges, ev_halo, ev_int, ev_c2x, ev_reach[0], ev_reach[1], ev_reach[2], ev_slack })
             if (ev) hipEventDestroy(ev);
         if (reach_pinned) hipHostFree(reach_pinned);
         if (comm_stream) hipStreamDestroy(comm_stream);
@@ -424,9 +427,17 @@ struct Engine : EngineBase {
     // compute stream holds so far, and the compute stream continues behind it.  One stream per communicator: RCCL orders a
     // communicator's operations by issue order, and two streams sharing one would be serialised in ways the schedule
     // does not show (round-2 verdict).
+    // Schedule 0 (a pass, then its exchange) overlaps nothing, so there the one stream is the compute stream itself and no
+    // event is needed: a cross-stream dependency costs about 14 us each way on this runtime (measured: 240 passes per step
+    // with an event pair each = 6.7 ms of a 26 ms slab step, profiles/r3e_*).
+    bool comm_on_compute_stream() const { return S->overlap_plan == 0; }
     template <class F>
     int comm_op(F&& op, const char* what)
     {
+        if (comm_on_compute_stream()) {
+            if (op(S->stream)) return fail(FS_ECOMM, "%s failed: %s", what, S->comm.last_error());
+            return FS_OK;
+        }
         HIP_TRY(hipEventRecord(ev_c2x, S->stream));
         HIP_TRY(hipStreamWaitEvent(comm_stream, ev_c2x, 0));
         if (op(comm_stream)) return fail(FS_ECOMM, "%s failed: %s", what, S->comm.last_error());
@@ -485,7 +496,7 @@ struct Engine : EngineBase {
     int slab_barrier()
     {
         HIP_TRY(hipStreamSynchronize(S->stream));
-        if (S->comm.barrier(comm_stream, red)) return fail(FS_ECOMM, "barrier: %s", S->comm.last_error());
+        if (S->comm.barrier(comm_on_compute_stream() ? S->stream : comm_stream, red)) return fail(FS_ECOMM, "barrier: %s", S->comm.last_error());
         return FS_OK;
     }
     // the largest `v` of any rank, the same bits on every rank (host-blocking; tuning only)
@@ -541,6 +552,8 @@ struct Engine : EngineBase {
             }
             for (int mode : modes) {
                 double ms = 0.0;
+                HIP_TRY(hipDeviceSynchronize());         // the transport's stream changes with the schedule: nothing may be in flight
+                S->overlap_plan = mode;
                 for (int rep = 0; rep < 2; ++rep) {          // the second chain is the timed one
                     if ((rc = slab_barrier())) return rc;
                     HIP_TRY(hipEventRecord(rel.e0, S->stream));
@@ -570,6 +583,7 @@ struct Engine : EngineBase {
             if ((rc = choose_pair_shape(src, rhs, b, a, inv_c))) return rc;
         }
         if (S->cus_plan < 0) S->cus_plan = 0;
+        HIP_TRY(hipDeviceSynchronize());
         S->overlap_plan = best_mode;
         if (S->comm.rank == 0 && !S->quiet)
             fprintf(stderr, "fluidsim: communication schedule overlap=%d, %d CUs kept free (timed: slowest rank %.3f ms per %d-sweep pass)\n",
@@ -627,7 +641,7 @@ struct Engine : EngineBase {
             HIP_TRY(hipStreamWaitEvent(S->stream, ev_halo, 0));
         } else {
             launch_pass(S->stream, lv, rb, src, rhs, dst, b, a, inv_c, 1, g.D);
-            return comm_op(exchange, "halo exchange");
+            return comm_op(exchange, "halo exchange");   // schedule 0: on the compute stream; a thin slab of schedule 1 / 2: through the events
         }
         return FS_OK;
     }
@@ -1214,7 +1228,13 @@ struct Engine : EngineBase {
             const T a = diffusion_a();
             if ((rc = solve_begin(dens_run, 0, slot[FS_DENS], slot[FS_BUFFER], a, (T)1 + (T)6 * a, S->acc))) return rc;   // :283
             if ((rc = solve_passes(dens_run, (int)dens_run.plan.size() / 2))) return rc;
+            HIP_TRY(hipEventRecord(ev_slack, S->stream));
         }
+        // was the device still busy with that work when the advection that waited for its reach had been queued?
+        auto slack_check = [&]() {
+            if (!split) return;
+            if (hipEventQuery(ev_slack) == hipErrorNotReady) ++S->n_reach_hidden; else ++S->n_reach_exposed;
+        };
         if (S->fuse_advect && slot[FS_VX] != slot[FS_VX_PREV] && slot[FS_VY] != slot[FS_VY_PREV] &&
             slot[FS_VZ] != slot[FS_VZ_PREV]) {
             // :125-127 in one pass (the three traces only chain through the cell's own values)
@@ -1223,15 +1243,18 @@ struct Engine : EngineBase {
             for (int k = 0; k < 3; ++k)                  // :125-127
                 if ((rc = advect(k + 1, V[k], V0[k]))) return rc;
         }
+        slack_check();
         if ((rc = project())) return rc;                 // :130
         if (split) {
             int res;
             if ((rc = solve_end(dens_run, &res))) return rc;
             adopt(FS_DENS, res);
+            HIP_TRY(hipEventRecord(ev_slack, S->stream));
         } else if (!S->elide_dead) {                     // :135 (its result is overwritten by :136)
             if ((rc = diffuse_T(0, FS_DENS, FS_BUFFER))) return rc;
         }
         if ((rc = advect(0, FS_DENS, FS_BUFFER))) return rc;   // :136
+        slack_check();
         S->step_no++;
         if (S->in_run && S->dump_every > 0 && (S->step_no % S->dump_every) == 0) return dump_frame();   // :140-148
         return FS_OK;
@@ -1839,6 +1862,8 @@ int fs_get_int(fs_sim* s, const char* name, int* out)
     else if (n == "reach_waits") *out = (int)s->n_reach_waits;            // waits for an asynchronously delivered reach ...
     else if (n == "reach_waits_blocked") *out = (int)s->n_reach_blocked;  // ... that found it not yet delivered
     else if (n == "reach_wait_us") *out = (int)(s->reach_wait_ms * 1e3);  // host time spent blocked in them
+    else if (n == "reach_hidden") *out = (int)s->n_reach_hidden;          // advections queued while the device still had the work placed before them ...
+    else if (n == "reach_exposed") *out = (int)s->n_reach_exposed;        // ... and after it had run dry (a bubble on the device)
     else return fail(FS_EINVAL, "unknown int member '%s'", name);
     return FS_OK;
 }

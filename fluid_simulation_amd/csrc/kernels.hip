@@ -1211,10 +1211,17 @@ __global__ __launch_bounds__(256) void advect_kernel(GridDesc g, SlabCtx sc, int
     const T one = (T)1, half = (T)0.5;
     T u = (T)0;
     if (!(f & F_SOLID)) {
-        const T own = prev[c + prev_zshift];
-        const T ux = (b == 1) ? own : vx[c];             // :380-382
-        const T uy = (b == 2) ? own : vy[c];
-        const T uz = (b == 3) ? own : vz[c];
+        // :380-382: the component being advected is carried by its own pre-advection value; the density (b = 0) by the
+        // current velocity alone -- its own value is not read at all (4 of 24 streamed bytes per cell)
+        T ux, uy, uz;
+        if (b == 0) {                                    // uniform
+            ux = vx[c]; uy = vy[c]; uz = vz[c];
+        } else {                                         // (the array being written is never read: `field` is restrict)
+            const T own = prev[c + prev_zshift];
+            ux = (b == 1) ? own : vx[c];
+            uy = (b == 2) ? own : vy[c];
+            uz = (b == 3) ? own : vz[c];
+        }
         if constexpr (TAB) {
             u = back_trace_tab<T>(g, sc, prev, prev_zshift, tab, x, y, z, ux, uy, uz, kx, ky, kz);
         } else {

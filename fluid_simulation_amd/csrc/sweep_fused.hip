@@ -73,9 +73,13 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     constexpr int BY = NYW * RY, TW = NXW * 256 + 8, RW = NXW * 256;
     constexpr int OV = NL - 1;                           // rows / planes a band / chunk loses per side
     constexpr int ES = (int)sizeof(T);
-    static_assert(((NL - 1) * 2 * BY * TW + NL * (BY - 2) * RW) * ES <= 160 * 1024, "LDS budget");
+    // WALLSEL = 2, the "lean interior" experiment (round-2 verdict, item 5): no right-hand-side ring -- the later levels re-read
+    // the rhs rows from memory (L2 / MALL hits) -- which frees 61 KB of LDS for 16-row bands, and only the wall-free body
+    // (workgroups that touch no wall).  See DESIGN.md section 4 for what it measured.
+    constexpr bool RS = (WALLSEL != 2);
+    static_assert(((NL - 1) * 2 * BY * TW + (RS ? NL * (BY - 2) * RW : 0)) * ES <= 160 * 1024, "LDS budget");
     __shared__ T ring[NL - 1][2][BY][TW];                // [level-1][plane & 1][tile row][x + 3]
-    __shared__ T rsave[NL][BY - 2][RW];                  // thread-private: rhs of the last NL planes
+    __shared__ T rsave[RS ? NL : 1][RS ? BY - 2 : 1][RW];   // thread-private: rhs of the last NL planes
 
     const int v = xcd_contiguous(blockIdx.x, nblk);
     const int band = v % nbands, zc = v / nbands;
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
                     relax4(L0[I1][r], eL[r], eR[r], ym, yp, L0[I0][r], L0[I2][r], rcur[r], u);
                     settle4(u, flc[r], L1[I2][r]);
                     publish(IC<0>{}, zl, r, u, L1[I2][r]);
-                    if (t >= 1 && t <= BY - 2) lds_set(&rs_put[t - 1][xl], rcur[r]);
+                    if (RS && t >= 1 && t <= BY - 2) lds_set(&rs_put[t - 1][xl], rcur[r]);
                     if (wall_lo1) face4(u, b == 3, L1[I1][r]);      // ghost plane z = 0 takes plane 0's slot, :208-210
                     if (wall_hi1) face4(u, b == 3, gz1[r]);         // ghost plane z = D+1 waits for its slot, :212-214
                 }
@@ -330,6 +334,15 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         // next plane's level-0 data, one iteration ahead.  Unconditional (a conditional load merges
         // with the old register contents, and the merge waits for the load); past the last plane the
         // same plane is fetched again and never used.
+        // lean variant: the right-hand sides of the two older planes, issued BEFORE the prefetch (memory returns in order:
+        // a wait for these must not wait for the next plane's loads as well)
+        T rh2[RS ? 1 : RY][4], rh3[RS ? 1 : RY][4];
+        if constexpr (!RS) {
+            const char* rp2 = plane_of(rhs, max(zl - 1, lo1));
+            const char* rp3 = plane_of(rhs, max(zl - 2, lo1));
+#pragma unroll
+            for (int r = 0; r < RY; ++r) { ld4(rp2 + oc[r], rh2[r]); ld4(rp3 + oc[r], rh3[r]); }
+        }
         __builtin_amdgcn_sched_barrier(0);               // pin the loads here: left alone, the scheduler sinks them to the
         load_core(min(zl + 2, zmax0), L0[I0]);           // end of the iteration to shorten live ranges, and the next
         load_side(min(zl + 1, zmax1));                   // iteration then starts by waiting a full memory latency
@@ -344,7 +357,11 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
                     const int y = y0 + r, t = ty0 + r;
                     if (y >= r2lo && y <= r2hi) {        // wave-uniform
                         T rh[4], u[4];
-                        lds_get(&rs_get2[t - 1][xl], rh);
+                        if constexpr (RS) lds_get(&rs_get2[t - 1][xl], rh);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rh[e] = rh2[r][e];
+                        }
                         next_row(IC<0>{}, P2, r, L1[I0], L1[I1], L1[I2], rh, u);
                         if (lane_on) {
                             settle4(u, kl[I2][r], L2[I2][r]);
@@ -383,7 +400,11 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
                     const int y = y0 + r, t = ty0 + r;
                     if (y >= r3lo && y <= r3hi) {
                         T rh[4], u[4];
-                        lds_get(&rsave[I1][t - 1][xl], rh);
+                        if constexpr (RS) lds_get(&rsave[I1][t - 1][xl], rh);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rh[e] = rh3[r][e];
+                        }
                         next_row(IC<NL - 2>{}, P3, r, L2[I0], L2[I1], L2[I2], rh, u);
                         if (lane_on) store_final(P3, r, u, kl[I1][r]);
                     }
@@ -416,7 +437,8 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     };
     // a workgroup needs the general body if one of its rows is a wall row or one of its level planes a wall plane
     const bool interior = (s > 0) && (s + BY - 1 < H) && (!lo_wall || lo1 >= 2) && (!hi_wall || hi1 <= D - 1);
-    if (WALLSEL == 1 && interior) run(IC<0>{});
+    if constexpr (WALLSEL == 2) run(IC<0>{});
+    else if (WALLSEL == 1 && interior) run(IC<0>{});
     else run(IC<1>{});
 }
 
@@ -531,6 +553,16 @@ void launch_jacobi_fused<float>(hipStream_t st, const SweepTune& tune, const Gri
     if (plan < 0) plan = 0;
     const int alt = plan >> 3, shape = plan & 7;
 #define FS_F(NL, NX, NY, RY) launch_fused_v<float, NL, NX, NY, RY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first)
+    if (levels == 3 && tune.abl == 16 && g.W == 512 && sc.lo_wall && sc.hi_wall && z_first == 1 && z_last == g.D && second_first < 0) {
+        // EXPERIMENT, timing only (wrong at the walls): every workgroup runs the lean interior body in 16-row bands
+        constexpr int BY = 16;
+        const int nbands = fused_bands<3>(g.H, BY);
+        const int nzc = alt == 0 ? 5 : alt == 1 ? 6 : 4;
+        const int zc_len = (g.D + nzc - 1) / nzc, nblk = nbands * nzc;
+        hipLaunchKernelGGL((jacobi_fused_kernel<float, 3, 2, 8, 2, true, false, 2>), dim3(nblk), dim3(1024), 0, st, g, sc, src, rhs, dst, flags,
+                           b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk);
+        return;
+    }
     if (levels == 3) {
         // Two rows per wave throughout (three rows and 8 waves were slower: the instruction stream of a wave
         // is what limits this kernel).  Rows up to 256 cells: bands of 20, 16 or 12 rows (the smaller ones trade
