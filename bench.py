@@ -176,7 +176,7 @@ def slab_parity_check(F, fsdist, dist, rank, world, transport, ctl_device):
     ws = whole.stats(F.VX)                               # (sum, min, max) over the global grid
     whole.close()
     bad, schedules = [], {}
-    for overlap in ("auto", "0", "1", "2"):
+    for overlap in ("auto", "0", "1", "2") + (("3",) if transport == "ipc" else ()):
         slab = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0, overlap=overlap)
         uid = fsdist.share_unique_id(dist, lambda: F.comm_unique_id(transport), rank, device=ctl_device)
         slab.comm_init(rank, world, uid)
@@ -224,7 +224,7 @@ def main():
                          "copies between the rank processes (csrc/ipc.h); with one GPU per rank an alternative to RCCL, with "
                          "fewer GPUs than ranks a development rehearsal (ranks share GPUs; never a result).  shm: the host-"
                          "staged synchronous development transport; never a result")
-    ap.add_argument("--overlap", default="auto", choices=["auto", "0", "1", "2"],
+    ap.add_argument("--overlap", default="auto", choices=["auto", "0", "1", "2", "3"],
                     help="communication schedule of the slab passes (fs_set_option \"overlap\"); auto = timed over the real transport")
     ap.add_argument("--comm-cus", default="0", help="CUs kept free of solver workgroups for the transport: 0 (default), N, or auto")
     args = ap.parse_args()
@@ -394,8 +394,8 @@ def main():
         # rank's time per pass of each candidate decides) and what the slab steps cost the host
         "comm": None if world == 1 else {
             "overlap_plan": sim._geti("overlap_plan"), "comm_cus": sim._geti("comm_cus_plan"),
-            "candidates_ms_per_pass": {"overlap=%d%s" % (k % 3, ", CU mask" if k >= 3 else ""): sim._getf("overlap%d_ms" % k)
-                                       for k in range(6) if sim._getf("overlap%d_ms" % k) > 0},
+            "candidates_ms_per_pass": {"overlap=%d%s" % (k % 4, ", CU mask" if k >= 4 else ""): sim._getf("overlap%d_ms" % k)
+                                       for k in range(8) if sim._getf("overlap%d_ms" % k) > 0},
             "comm_family_ms_per_step": fam["comm"][0] / args.steps,
             "comm_family_note": "halo refreshes outside the solver, advection gathers and reductions, waits included; the "
                                 "solver's own exchanges fall inside the sweep families",

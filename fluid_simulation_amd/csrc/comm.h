@@ -277,6 +277,38 @@ struct Comm {
     {
         if (ipc) { ipc->destroy(); delete ipc; ipc = nullptr; null_transport = true; }
     }
+    // FSIPC only: solver passes may store their boundary planes straight into the neighbours' halo planes
+    bool can_push() const { return ipc != nullptr && active(); }
+    // the PeerPush offsets for a pass that writes the local array `dst` (plane z at dst + z * sz)
+    int peer_push(const void* dst, const GridDesc& g, size_t elem, int planes, PeerPush* out)
+    {
+        *out = PeerPush();
+        if (!can_push()) return 0;
+        const char* d = static_cast<const char*>(dst);
+        const long slab = (long)g.D * g.sz * (long)elem;
+        if (rank > 0) {
+            const char* p = ipc->peer_address(rank - 1, d, 1, &err);
+            if (!p) return -1;
+            out->lo = (long)(p - d) + slab;              // my plane z is the lower neighbour's plane D + z
+        }
+        if (rank < nranks - 1) {
+            const char* p = ipc->peer_address(rank + 1, d, 1, &err);
+            if (!p) return -1;
+            out->hi = (long)(p - d) - slab;              // my plane z is the upper neighbour's plane z - D
+        }
+        out->planes = planes;
+        return 0;
+    }
+    // both z neighbours have completed everything they queued before this point (stream-ordered, FSIPC)
+    int handshake(hipStream_t st)
+    {
+        if (!can_push()) return 0;
+        int peers[2], n = 0;
+        if (rank > 0) peers[n++] = rank - 1;
+        if (rank < nranks - 1) peers[n++] = rank + 1;
+        return ipc->handshake(st, peers, n, &err);
+    }
+
     // a bounded device-side wait gave up (lost peer): the results since then are void
     int check()
     {

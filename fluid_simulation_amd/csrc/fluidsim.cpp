@@ -119,7 +119,7 @@ struct fs_sim {
                                                    // solve placed before them (hidden) / after it had run dry (exposed: a bubble)
     double reach_wait_ms = 0.0;  // host time spent in them
     int overlap_plan = -1, cus_plan = -1;          // what "auto" chose (or the forced values), -1 before the first slab solve
-    double overlap_ms[6] = {0, 0, 0, 0, 0, 0};     // slowest rank's ms per pass of each timed candidate (overlap 0/1/2 x cu mask off/on)
+    double overlap_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // slowest rank's ms per pass of each timed candidate (overlap 0..3 x cu mask off/on)
     bool debug_poison = false;   // fill the gathered advection source with NaN bit patterns before each gather
     int last_reach = 0;          // planes of reach used by the most recent slab advection
     // device
@@ -430,7 +430,7 @@ struct Engine : EngineBase {
     // Schedule 0 (a pass, then its exchange) overlaps nothing, so there the one stream is the compute stream itself and no
     // event is needed: a cross-stream dependency costs about 14 us each way on this runtime (measured: 240 passes per step
     // with an event pair each = 6.7 ms of a 26 ms slab step, profiles/r3e_*).
-    bool comm_on_compute_stream() const { return S->overlap_plan == 0; }
+    bool comm_on_compute_stream() const { return S->overlap_plan == 0 || S->overlap_plan == 3; }
     template <class F>
     int comm_op(F&& op, const char* what)
     {
@@ -456,19 +456,20 @@ struct Engine : EngineBase {
     // ---- linearSolver (simulation.cpp:251-273) -----------------------------------------
     // One pass over memory that applies `levels` (1, 2 or 3) Jacobi sweeps to planes zf..zl (and, with
     // second >= 0, to the equally long range starting there).
+    // push: the pass also stores the planes its z neighbours need into their halo planes (plain Jacobi passes, FSIPC)
     void launch_pass(hipStream_t st, int levels, bool rb, const T* src_, const T* rhs_, T* dst_, int b, T a, T inv_c, int zf,
-                     int zl, int second = -1)
+                     int zl, int second = -1, const fs::PeerPush* push = nullptr)
     {
         const T omega = rb ? rb_omega : (T)0;
         if (levels == 3)
-            fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 3, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, triple_alt, second);
+            fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 3, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, triple_alt, second, push);
         else if (levels == 2 && !rb && pair_shape >= FUSED2)
-            fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 2, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape - FUSED2, second);
+            fs::launch_jacobi_fused<T>(st, S->tune, g, sc, 2, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, pair_shape - FUSED2, second, push);
         else if (levels == 2)
             fs::launch_jacobi_pair<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl,
-                                      pair_shape >= FUSED2 ? pair_plan_rb : pair_shape, second, omega, rb_damped);
+                                      pair_shape >= FUSED2 ? pair_plan_rb : pair_shape, second, omega, rb_damped, push);
         else
-            fs::launch_jacobi<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, second);
+            fs::launch_jacobi<T>(st, S->tune, g, sc, src_, rhs_, dst_, kill, b, a, inv_c, zf, zl, second, push);
     }
     bool two_sweep_kernels() const
     {
@@ -527,6 +528,7 @@ struct Engine : EngineBase {
         if (S->overlap >= 0) modes.push_back(S->overlap);
         else if (g.D < 2 * lv + 8) modes.push_back(0);                 // too thin for a boundary/interior split: one schedule
         else modes = { 1, 0, 2 };
+        if (S->overlap < 0 && S->comm.can_push()) modes.push_back(3);   // FSIPC: passes that store into the neighbours' halos
         if (modes.size() == 1 && !auto_cus) {
             S->overlap_plan = modes[0];
             if (S->cus_plan < 0) S->cus_plan = 0;
@@ -571,7 +573,7 @@ struct Engine : EngineBase {
                 }
                 double worst = ms;
                 if ((rc = rank_max(ms, &worst))) return rc;
-                S->overlap_ms[3 * mask + mode] = worst;
+                S->overlap_ms[4 * mask + mode] = worst;
                 if (tune_log)
                     fprintf(stderr, "fluidsim tune: rank %d overlap=%d cu mask %s: %.4f ms per pass here, %.4f on the slowest rank\n",
                             S->comm.rank, mode, mask ? "on" : "off", ms, worst);
@@ -607,6 +609,18 @@ struct Engine : EngineBase {
     int slab_pass(int mode, int lv, int e, bool first, bool last, bool rb, const T* src, const T* rhs, T* dst, int b, T a, T inv_c)
     {
         auto exchange = [&](hipStream_t st) { return S->comm.exchange_halo(st, dst, g, sizeof(T), S->D, e); };
+        if (mode == 3 && !rb && S->comm.can_push()) {
+            // Push (FSIPC): the pass stores the `e` outermost planes per side straight into the neighbours' halo planes; a
+            // handshake on the same stream ("my pass is complete" both ways) is all that separates it from the next
+            // pass -- no boundary launch, no copy, no second stream, no event.  The neighbour's halo of this array is
+            // free: its last reader there was the neighbour's previous pass, which the previous handshake covered.
+            fs::PeerPush pp;
+            if (S->comm.peer_push(dst, g, sizeof(T), e, &pp)) return fail(FS_ECOMM, "push exchange: %s", S->comm.last_error());
+            launch_pass(S->stream, lv, false, src, rhs, dst, b, a, inv_c, 1, g.D, -1, &pp);
+            if (S->comm.handshake(S->stream)) return fail(FS_ECOMM, "handshake: %s", S->comm.last_error());
+            return FS_OK;
+        }
+        if (mode == 3) mode = 0;                          // a pass the push kernels do not cover (red-black): pass, then copy exchange
         if (g.D < 2 * e + 8) mode = 0;                    // too thin to split into boundary and interior
         const int in_lo = sc.lo_wall ? 1 : e + 1, in_hi = sc.hi_wall ? g.D : g.D - e;
         auto boundary = [&](hipStream_t st) {
@@ -676,6 +690,10 @@ struct Engine : EngineBase {
             // a fused pass recomputes the lower levels of the neighbours' boundary planes: it reads the
             // right-hand side there, so its halo planes must be current
             if ((rc = halo(arr[rhs]))) return rc;
+        } else if (npass > 0 && S->overlap_plan == 3 && S->comm.can_push()) {
+            // push schedule: the first pass writes into the neighbours' arrays, so whatever they queued before this solve
+            // has to be complete (the exchange above is such a handshake; without it, one is issued)
+            if (S->comm.handshake(S->stream)) return fail(FS_ECOMM, "handshake: %s", S->comm.last_error());
         }
         return FS_OK;
     }
@@ -1788,8 +1806,8 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
     } else if (k == "overlap") {
         if (s->eng && s->overlap_plan >= 0) return fail(FS_EINVAL, "overlap must be set before the first solve");
         s->overlap = (v == "auto") ? -1 : atoi(value);
-        if (s->overlap < -1 || s->overlap > 2 || (v != "auto" && v != "0" && v != "1" && v != "2"))
-            return fail(FS_EINVAL, "overlap: auto | 0 | 1 | 2");
+        if (s->overlap < -1 || s->overlap > 3 || (v != "auto" && v != "0" && v != "1" && v != "2" && v != "3"))
+            return fail(FS_EINVAL, "overlap: auto | 0 | 1 | 2 | 3");
     } else if (k == "comm_cus") {
         if (s->eng) return fail(FS_EINVAL, "comm_cus must be set before first use");
         s->comm_cus = (v == "auto") ? -1 : atoi(value);
@@ -1882,8 +1900,8 @@ int fs_get_float(fs_sim* s, const char* name, float* out)
     if (!s || !name || !out) return fail(FS_EINVAL, "null argument");
     std::string n = name;
     if (n == "dt") *out = s->dt; else if (n == "diff") *out = s->diff; else if (n == "visc") *out = s->visc;
-    else if (n.size() == 11 && n.compare(0, 7, "overlap") == 0 && n.compare(8, 3, "_ms") == 0 && n[7] >= '0' && n[7] <= '5')
-        *out = (float)s->overlap_ms[n[7] - '0'];   // "overlap<k>_ms": slowest rank's ms per pass of candidate k = overlap mode + 3 * (CU mask on), 0 = not timed
+    else if (n.size() == 11 && n.compare(0, 7, "overlap") == 0 && n.compare(8, 3, "_ms") == 0 && n[7] >= '0' && n[7] <= '7')
+        *out = (float)s->overlap_ms[n[7] - '0'];   // "overlap<k>_ms": slowest rank's ms per pass of candidate k = overlap mode + 4 * (CU mask on), 0 = not timed
     else return fail(FS_EINVAL, "unknown float member '%s'", name);
     return FS_OK;
 }

@@ -284,6 +284,27 @@ struct IpcTransport {
         return 0;
     }
 
+    // "Everything I queued before this has completed" to each of `peers`, and wait for the same from them: what separates
+    // two solver passes that store their boundary planes straight into the neighbours' halo planes (PeerPush, kernels.h).
+    int handshake(hipStream_t st, const int* peers, int n, std::string* err)
+    {
+        if (open(err)) return -1;
+        ++seq;
+        ++ops;
+        IpcSyncArgs a;
+        a.nstore = a.nwait = n;
+        a.seq = seq;
+        a.err = &dhdr->error;
+        a.timeout_ticks = timeout_ticks;
+        for (int i = 0; i < n; ++i) {
+            a.store[i] = &dhdr->done[peers[i]][rank];
+            a.wait[i] = &dhdr->done[rank][peers[i]];
+        }
+        hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, st, a);
+        if (hipGetLastError() != hipSuccess) { *err = "FSIPC: launching the handshake kernel failed"; return -1; }
+        return 0;
+    }
+
     // {sum, min, max} over the ranks, in place in device memory; every rank computes the same bits
     int reduce3(hipStream_t st, double* d3, std::string* err)
     {

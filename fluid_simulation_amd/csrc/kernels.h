@@ -59,12 +59,22 @@ struct SweepTune {
     int two_kind = 0;         // which two-sweep kernel: 0 = timed choice, 1 = jacobi_pair_kernel only, 2 = jacobi_fused_kernel<NL=2> only
 };
 
+// z-slab "push" exchange (FSIPC transport, csrc/ipc.h): a solver pass stores the planes its neighbours need next straight
+// into THEIR halo planes (peer-mapped arrays) beside its own -- no boundary launch, no copy, no second stream.
+// lo / hi = byte offset from a cell of `dst` to the same cell of the lower / upper neighbour's copy of that plane in the
+// neighbour's halo (0 = no neighbour on that side), planes = how many of the slab's outermost planes per side go over.
+struct PeerPush {
+    long lo = 0, hi = 0;
+    int planes = 0;
+};
+
 // NOTE: the sweep launchers take the KILL-byte array (launch_build_kill), not the flag bytes.
 template <class T>
 void launch_jacobi(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
-                   T* dst, const uint8_t* kill, int b, T a, T inv_c, int z_first, int z_last, int second_first = -1);
+                   T* dst, const uint8_t* kill, int b, T a, T inv_c, int z_first, int z_last, int second_first = -1,
+                   const PeerPush* push = nullptr);
 // second_first >= 0: ALSO compute the equally long range starting there, in the same launch (a
-// slab's two boundary regions)
+// slab's two boundary regions); push: see PeerPush (plain Jacobi passes over one range only)
 
 // Two sweeps in one pass (temporal blocking); same result as two launch_jacobi calls.
 // Needs W <= 1024; on a z-slab additionally two halo planes per side (g.zh == 2), current in
@@ -74,7 +84,7 @@ bool pair_supported(const SweepTune& tune, const GridDesc& g, const SlabCtx& sc)
 template <class T>
 void launch_jacobi_pair(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
                         T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int shape,
-                        int second_first = -1, T omega = (T)0, bool damped = false);
+                        int second_first = -1, T omega = (T)0, bool damped = false, const PeerPush* push = nullptr);
 // omega != 0: one red-black SOR iteration instead; with `damped`, two Jacobi sweeps damped by omega (q + omega*(r - q))
 // NL = `levels` (2 or 3) sweeps per pass, register-centred (sweep_fused.hip): fp32 x 3 for rows up to 512
 // cells, fp32 x 2 for rows of 513..1024 cells, fp64 x 2 for rows up to 512 cells.  On a z-slab `src` needs
@@ -87,7 +97,7 @@ int fused_shape_count(const GridDesc& g, int levels);
 template <class T>
 void launch_jacobi_fused(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int levels, const T* src,
                          const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int plan,
-                         int second_first = -1);
+                         int second_first = -1, const PeerPush* push = nullptr);
 // number of workgroup shapes (0 .. count-1) worth timing for this grid; results do not depend on the shape
 template <class T>
 int pair_shape_count(const GridDesc& g);

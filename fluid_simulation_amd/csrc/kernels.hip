@@ -40,12 +40,12 @@ struct AuxIn {
     unsigned fl[RY];     // kill byte of the lane's four cells: bits 0-3 solid, bits 4-7 solid-or-near
 };
 
-template <class T, int RY, int ABL>
+template <class T, int RY, int ABL, bool PUSH>
 __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                             const T* __restrict__ rhs, T* __restrict__ dst,
                                                             const uint8_t* __restrict__ flags, int b, T a, T inv_c,
                                                             int z_first, int z_last, int zc_len, int z_stride, int nxw,
-                                                            int nybg, int nblk)
+                                                            int nybg, int nblk, PeerPush pp)
 {
     const int v = xcd_contiguous(blockIdx.x, nblk);
     const int xw = v % nxw;
@@ -154,9 +154,10 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
                     // cells past W: the outflow ghost copies u(W) (:191); row padding stays 0
                     st.e[e] = (x <= W) ? (kill ? zero : u[e]) : ((x == W + 1) ? ghost_src : zero);
                 }
-                if (!(ABL & 8) || st.e[0] == (T)123456789) *reinterpret_cast<V4<T>*>(dst + base) = st;
-                if (x0 == 1) dst[base - 1] = (b == 1) ? -u[0] : u[0];                            // :189-190
-                if (full_group && x0 + 3 == W) dst[base + 4] = u[3];                            // :191
+                const long dl = (PUSH && z <= pp.planes) ? pp.lo : 0, dh = (PUSH && z > D - pp.planes) ? pp.hi : 0;   // wave-uniform
+                if (!(ABL & 8) || st.e[0] == (T)123456789) put<PUSH>(reinterpret_cast<V4<T>*>(dst + base), st, dl, dh);
+                if (x0 == 1) put<PUSH>(dst + base - 1, (b == 1) ? -u[0] : u[0], dl, dh);        // :189-190
+                if (full_group && x0 + 3 == W) put<PUSH>(dst + base + 4, u[3], dl, dh);         // :191
                 const bool yface = (y == 1) || (y == H);                                        // wave-uniform
                 const bool zface = (z == 1 && sc.lo_wall) || (z == D && sc.hi_wall);            // wave-uniform
                 if (yface || zface) {
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
                         gy.e[e] = in ? ((b == 2) ? -u[e] : u[e]) : zero;                        // :198-201
                         gz.e[e] = in ? ((b == 3) ? -u[e] : u[e]) : zero;                        // :208-214
                     }
-                    if (y == 1) *reinterpret_cast<V4<T>*>(dst + base - g.sy) = gy;
-                    if (y == H) *reinterpret_cast<V4<T>*>(dst + base + g.sy) = gy;
+                    if (y == 1) put<PUSH>(reinterpret_cast<V4<T>*>(dst + base - g.sy), gy, dl, dh);
+                    if (y == H) put<PUSH>(reinterpret_cast<V4<T>*>(dst + base + g.sy), gy, dl, dh);
                     if (z == 1 && sc.lo_wall) *reinterpret_cast<V4<T>*>(dst + base - g.sz) = gz;
                     if (z == D && sc.hi_wall) *reinterpret_cast<V4<T>*>(dst + base + g.sz) = gz;
                 }
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void jacobi_sweep_kernel(GridDesc g, SlabCtx s
 template <class T, int RY, int ABL>
 static void launch_jacobi_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
                             const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last,
-                            int second_first)
+                            int second_first, const PeerPush* push)
 {
     const int nxw = (g.W + 255) / 256;
     const int nyb = (g.H + RY - 1) / RY;
@@ -198,9 +199,9 @@ static void launch_jacobi_v(hipStream_t st, const SweepTune& tune, const GridDes
     if (second_first >= 0) {
         // two equally long ranges (the slab's two boundary regions) as two chunks of one launch
         const int last2 = second_first + planes - 1;
-        hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY, ABL>), dim3((unsigned)(per_layer * 2)), dim3(256), 0, st, g, sc, src,
+        hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY, ABL, false>), dim3((unsigned)(per_layer * 2)), dim3(256), 0, st, g, sc, src,
                            rhs, dst, flags, b, a, inv_c, z_first, last2, planes, second_first - z_first, nxw, nybg,
-                           (int)(per_layer * 2));
+                           (int)(per_layer * 2), PeerPush());
         return;
     }
     // enough z chunks for ~target_blocks blocks, but chunks of at least 8 planes (each chunk
@@ -212,16 +213,20 @@ static void launch_jacobi_v(hipStream_t st, const SweepTune& tune, const GridDes
     if (tune.zc_len > 0) zc_len = tune.zc_len < planes ? tune.zc_len : planes;
     const int nzc = (planes + zc_len - 1) / zc_len;
     const int nblk = (int)(per_layer * nzc);
-    hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY, ABL>), dim3(nblk), dim3(256), 0, st, g, sc, src, rhs, dst, flags, b,
-                       a, inv_c, z_first, z_last, zc_len, zc_len, nxw, nybg, nblk);
+    if (ABL == 0 && push && (push->lo || push->hi))
+        hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY, 0, true>), dim3(nblk), dim3(256), 0, st, g, sc, src, rhs, dst, flags, b,
+                           a, inv_c, z_first, z_last, zc_len, zc_len, nxw, nybg, nblk, *push);
+    else
+        hipLaunchKernelGGL((jacobi_sweep_kernel<T, RY, ABL, false>), dim3(nblk), dim3(256), 0, st, g, sc, src, rhs, dst, flags, b,
+                           a, inv_c, z_first, z_last, zc_len, zc_len, nxw, nybg, nblk, PeerPush());
 }
 
 template <class T>
 void launch_jacobi(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src, const T* rhs,
-                   T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int second_first)
+                   T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int second_first, const PeerPush* push)
 {
     if (z_last < z_first) return;
-#define FS_GO(RY, ABL) launch_jacobi_v<T, RY, ABL>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, second_first)
+#define FS_GO(RY, ABL) launch_jacobi_v<T, RY, ABL>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, second_first, push)
     if (tune.abl == 0) {
         if (tune.ry == 4) FS_GO(4, 0);
         else FS_GO(2, 0);
@@ -238,9 +243,9 @@ void launch_jacobi(hipStream_t st, const SweepTune& tune, const GridDesc& g, con
 #undef FS_GO
 }
 template void launch_jacobi<float>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, const float*, const float*,
-                                   float*, const uint8_t*, int, float, float, int, int, int);
+                                   float*, const uint8_t*, int, float, float, int, int, int, const PeerPush*);
 template void launch_jacobi<double>(hipStream_t, const SweepTune&, const GridDesc&, const SlabCtx&, const double*,
-                                    const double*, double*, const uint8_t*, int, double, double, int, int, int);
+                                    const double*, double*, const uint8_t*, int, double, double, int, int, int, const PeerPush*);
 
 // =====================================================================================
 // Two Jacobi sweeps per pass over memory (temporal blocking), bit-identical with two
@@ -264,12 +269,12 @@ template void launch_jacobi<double>(hipStream_t, const SweepTune&, const GridDes
 // =====================================================================================
 // MODE: 0 = two Jacobi sweeps; 1 = one red-black iteration (solver=rbsor; coarse-level-style smoothing); 2 = two damped
 // Jacobi sweeps, q + omega*(r - q) in every cell (the level-0 smoother of solver=mg)
-template <class T, int NXW, int NYW, int MODE>
+template <class T, int NXW, int NYW, int MODE, bool PUSH>
 __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, SlabCtx sc, const T* __restrict__ src,
                                                                      const T* __restrict__ rhs, T* __restrict__ dst,
                                                                      const uint8_t* __restrict__ flags, int b, T a,
                                                                      T inv_c, int z_first, int z_last, int zc_len,
-                                                                     int z_stride, int nbands, int nblk, T omega)
+                                                                     int z_stride, int nbands, int nblk, T omega, PeerPush pp)
 {
     constexpr int RY = 2, BY = NYW * RY, TW = NXW * 256 + 8;
     // ring of four level-1 plane tiles (plane z lives in slot z & 3); column index = x + 3
@@ -414,9 +419,10 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
             V4<T> q;
 #pragma unroll
             for (int e = 0; e < 4; ++e) q.e[e] = st[e];
-            *reinterpret_cast<V4<T>*>(dst + base) = q;
-            if (x0 == 1) dst[base - 1] = (b == 1) ? -u[0] : u[0];                               // :189-190
-            if (full_group && x0 + 3 == W) dst[base + 4] = u[3];                               // :191
+            const long dl = (PUSH && zo <= pp.planes) ? pp.lo : 0, dh = (PUSH && zo > D - pp.planes) ? pp.hi : 0;   // wave-uniform
+            put<PUSH>(reinterpret_cast<V4<T>*>(dst + base), q, dl, dh);
+            if (x0 == 1) put<PUSH>(dst + base - 1, (b == 1) ? -u[0] : u[0], dl, dh);            // :189-190
+            if (full_group && x0 + 3 == W) put<PUSH>(dst + base + 4, u[3], dl, dh);             // :191
             const bool zlo_face = (zo == 1) && sc.lo_wall, zhi_face = (zo == D) && sc.hi_wall;
             if (y == 1 || y == H || zlo_face || zhi_face) {
                 T f[4];
@@ -424,8 +430,8 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
                 face4(u, b == 2, f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qq.e[e] = f[e];
-                if (y == 1) *reinterpret_cast<V4<T>*>(dst + base - g.sy) = qq;                  // :198-201
-                if (y == H) *reinterpret_cast<V4<T>*>(dst + base + g.sy) = qq;
+                if (y == 1) put<PUSH>(reinterpret_cast<V4<T>*>(dst + base - g.sy), qq, dl, dh);  // :198-201
+                if (y == H) put<PUSH>(reinterpret_cast<V4<T>*>(dst + base + g.sy), qq, dl, dh);
                 face4(u, b == 3, f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) qq.e[e] = f[e];
@@ -521,12 +527,15 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_pair_kernel(GridDesc g, 
 template <class T, int NXW, int NYW>
 static void launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
                           const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt,
-                          int second_first, T omega, bool damped)
+                          int second_first, T omega, bool damped, const PeerPush* push)
 {
     // omega == 0: two Jacobi sweeps; otherwise one red-black SOR iteration with that relaxation factor, or (damped)
     // two Jacobi sweeps damped by it
-    auto kernel = (omega == (T)0) ? jacobi_pair_kernel<T, NXW, NYW, 0>
-                                  : damped ? jacobi_pair_kernel<T, NXW, NYW, 2> : jacobi_pair_kernel<T, NXW, NYW, 1>;
+    const bool pushing = push && (push->lo || push->hi) && omega == (T)0 && second_first < 0;
+    const PeerPush pp = pushing ? *push : PeerPush();
+    auto kernel = pushing ? jacobi_pair_kernel<T, NXW, NYW, 0, true>
+                  : (omega == (T)0) ? jacobi_pair_kernel<T, NXW, NYW, 0, false>
+                  : damped ? jacobi_pair_kernel<T, NXW, NYW, 2, false> : jacobi_pair_kernel<T, NXW, NYW, 1, false>;
     constexpr int BY = NYW * 2;
     const int planes = z_last - z_first + 1;
     if (planes <= 0) return;
@@ -535,7 +544,7 @@ static void launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc&
         // two equally long ranges (the slab's two boundary regions) as two chunks of one launch
         hipLaunchKernelGGL(kernel, dim3(nbands * 2), dim3(NXW * NYW * 64), 0, st, g, sc, src,
                            rhs, dst, flags, b, a, inv_c, z_first, second_first + planes - 1, planes,
-                           second_first - z_first, nbands, nbands * 2, omega);
+                           second_first - z_first, nbands, nbands * 2, omega, pp);
         return;
     }
     // z chunks: each re-reads 4 level-0 planes and recomputes 2 level-1 planes, so keep them
@@ -567,7 +576,7 @@ static void launch_pair_v(hipStream_t st, const SweepTune& tune, const GridDesc&
     const int nzc = (planes + zc_len - 1) / zc_len;
     const int nblk = nbands * nzc;
     hipLaunchKernelGGL(kernel, dim3(nblk), dim3(NXW * NYW * 64), 0, st, g, sc, src, rhs,
-                       dst, flags, b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk, omega);
+                       dst, flags, b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk, omega, pp);
 }
 
 template <class T>
@@ -587,7 +596,7 @@ int pair_shape_count<double>(const GridDesc&) { return 1; }
 template <>
 void launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const float* src,
                                const float* rhs, float* dst, const uint8_t* flags, int b, float a, float inv_c, int z_first,
-                               int z_last, int shape, int second_first, float omega, bool damped)
+                               int z_last, int shape, int second_first, float omega, bool damped, const PeerPush* push)
 {
     // shape: 0 = 12 waves (768 threads, <=168 VGPRs), 2 = 10 waves, 1 = 8 waves, 3 = 16 waves (spills;
     // tuning tool only).  All shapes give identical results; the host driver times 0..count-1 once per
@@ -597,7 +606,7 @@ void launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const Grid
     const int alt = shape >> 3;                          // which of the three best chunk counts
     shape &= 7;
     if (tune.pair_shape > 0) shape = tune.pair_shape;
-#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped)
+#define FS_PAIR(NX, NY) launch_pair_v<float, NX, NY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped, push)
     if (nxw == 1) { if (shape == 1) FS_PAIR(1, 8); else if (shape == 2) FS_PAIR(1, 10); else if (shape == 3) FS_PAIR(1, 16); else FS_PAIR(1, 12); }
     else if (nxw == 2) { if (shape == 1) FS_PAIR(2, 4); else if (shape == 2) FS_PAIR(2, 5); else if (shape == 3) FS_PAIR(2, 8); else FS_PAIR(2, 6); }
     else if (nxw == 3) FS_PAIR(3, 4);
@@ -607,14 +616,14 @@ void launch_jacobi_pair<float>(hipStream_t st, const SweepTune& tune, const Grid
 template <>
 void launch_jacobi_pair<double>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const double* src,
                                 const double* rhs, double* dst, const uint8_t* flags, int b, double a, double inv_c,
-                                int z_first, int z_last, int shape, int second_first, double omega, bool damped)
+                                int z_first, int z_last, int shape, int second_first, double omega, bool damped, const PeerPush* push)
 {
     const int alt = shape < 0 ? 0 : (shape >> 3);
     const int nxw = (g.W + 255) / 256;   // LDS: 4 * BY * TW * 8 bytes must stay under 160 KB
-    if (nxw == 1) launch_pair_v<double, 1, 8>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped);
-    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped);
-    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped);
-    else launch_pair_v<double, 4, 2>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped);
+    if (nxw == 1) launch_pair_v<double, 1, 8>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped, push);
+    else if (nxw == 2) launch_pair_v<double, 2, 4>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped, push);
+    else if (nxw == 3) launch_pair_v<double, 3, 3>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped, push);
+    else launch_pair_v<double, 4, 2>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, omega, damped, push);
 }
 
 // =====================================================================================

@@ -30,6 +30,18 @@ __device__ __forceinline__ void write_face_ghosts(const GridDesc& g, const SlabC
     if (z == g.D && sc.hi_wall) q[c + g.sz] = (b == 3) ? -u : u;
 }
 
+// A store of a solver pass, and (PUSH) its copies into the neighbours' halo planes: dl / dh = PeerPush::lo / hi where the
+// plane being written is one the lower / upper neighbour needs, else 0 (wave-uniform).
+template <bool PUSH, class V>
+__device__ __forceinline__ void put(V* p, const V& v, long dl, long dh)
+{
+    *p = v;
+    if constexpr (PUSH) {
+        if (dl) *reinterpret_cast<V*>(reinterpret_cast<char*>(p) + dl) = v;
+        if (dh) *reinterpret_cast<V*>(reinterpret_cast<char*>(p) + dh) = v;
+    }
+}
+
 // Blocks are dealt round-robin over the 8 XCDs (block b lands on XCD b % 8, each with its
 // own 4 MiB L2).  Remap so that every XCD owns one contiguous range of work items and
 // y-adjacent tiles, which share halo rows, hit the same L2.  Affects speed only.

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
                                                                       const T* __restrict__ rhs, T* __restrict__ dst,
                                                                       const uint8_t* __restrict__ flags, int b, T a, T inv_c,
                                                                       int z_first, int z_last, int zc_len, int z_stride,
-                                                                      int nbands, int nblk)
+                                                                      int nbands, int nblk, PeerPush pp)
 {
     static_assert(NL == 2 || NL == 3, "two or three sweeps per pass");
     constexpr int BY = NYW * RY, TW = NXW * 256 + 8, RW = NXW * 256;
@@ -260,6 +260,8 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         T st[4];
         settle4(u, fl, st);
         char* base = reinterpret_cast<char*>(dst) + (long)zo * plane_b + oc[r];
+        // z-slab push exchange: the planes the neighbours need next also go straight into their halo planes (wave-uniform)
+        const long dl = (SLAB && zo <= pp.planes) ? pp.lo : 0, dh = (SLAB && zo > D - pp.planes) ? pp.hi : 0;
         if (FS_EXP_NT & 2) {
             Vec4<T> q;
 #pragma unroll
@@ -269,18 +271,18 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
             V4<T> q;
 #pragma unroll
             for (int e = 0; e < 4; ++e) q.e[e] = st[e];
-            *reinterpret_cast<V4<T>*>(base) = q;
+            put<SLAB>(reinterpret_cast<V4<T>*>(base), q, dl, dh);
         }
-        if (x0 == 1) *reinterpret_cast<T*>(base - ES) = (b == 1) ? -u[0] : u[0];                    // :189-190
-        if (full_group && x0 + 3 == W) *reinterpret_cast<T*>(base + 4 * ES) = u[3];                // :191
+        if (x0 == 1) put<SLAB>(reinterpret_cast<T*>(base - ES), (b == 1) ? -u[0] : u[0], dl, dh);   // :189-190
+        if (full_group && x0 + 3 == W) put<SLAB>(reinterpret_cast<T*>(base + 4 * ES), u[3], dl, dh);   // :191
         if (WALLS && (y == 1 || y == H)) {
             T f[4];
             V4<T> qq;
             face4(u, b == 2, f);
 #pragma unroll
             for (int e = 0; e < 4; ++e) qq.e[e] = f[e];
-            if (y == 1) *reinterpret_cast<V4<T>*>(base - row_b) = qq;                               // :198-201
-            if (y == H) *reinterpret_cast<V4<T>*>(base + row_b) = qq;
+            if (y == 1) put<SLAB>(reinterpret_cast<V4<T>*>(base - row_b), qq, dl, dh);               // :198-201
+            if (y == H) put<SLAB>(reinterpret_cast<V4<T>*>(base + row_b), qq, dl, dh);
         }
         const bool zlo_face = (zo == 1) && lo_wall_c, zhi_face = (zo == D) && hi_wall_c;
         if (zlo_face || zhi_face) {
@@ -456,8 +458,9 @@ static int fused_bands(int H, int BY)
 template <class T, int NL, int NXW, int NYW, int RY>
 static void launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, const T* src,
                            const T* rhs, T* dst, const uint8_t* flags, int b, T a, T inv_c, int z_first, int z_last, int alt,
-                           int second_first)
+                           int second_first, const PeerPush* push)
 {
+    const PeerPush pp = (push && second_first < 0) ? *push : PeerPush();
     constexpr int BY = NYW * RY, THREADS = NXW * NYW * 64;
     const int planes = z_last - z_first + 1;
     if (planes <= 0) return;
@@ -503,7 +506,7 @@ static void launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc
     // else the general one
 #define FS_LAUNCH(AL, SL, WS)                                                                                            \
     hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, AL, SL, WS>), dim3(nblk), dim3(THREADS), 0, st, g, sc, src, \
-                       rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk)
+                       rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk, pp)
     // The wall-free second body exists for the three-sweep kernel on lane-aligned whole-domain grids (the benchmark grids).
     // It is 9 % (512^3) to 14 % (256^3) faster per workgroup, but a pass ends with its slowest workgroup: it only pays when a
     // CU works through several workgroups (256^3: -2.5 %); with one workgroup per CU (512^3: 256 workgroups) the general
@@ -548,11 +551,11 @@ int fused_shape_count<double>(const GridDesc& g, int) { return (g.W <= 256) ? 1 
 template <>
 void launch_jacobi_fused<float>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int levels,
                                 const float* src, const float* rhs, float* dst, const uint8_t* flags, int b, float a,
-                                float inv_c, int z_first, int z_last, int plan, int second_first)
+                                float inv_c, int z_first, int z_last, int plan, int second_first, const PeerPush* push)
 {
     if (plan < 0) plan = 0;
     const int alt = plan >> 3, shape = plan & 7;
-#define FS_F(NL, NX, NY, RY) launch_fused_v<float, NL, NX, NY, RY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first)
+#define FS_F(NL, NX, NY, RY) launch_fused_v<float, NL, NX, NY, RY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, push)
     if (levels == 3 && tune.abl == 16 && g.W == 512 && sc.lo_wall && sc.hi_wall && z_first == 1 && z_last == g.D && second_first < 0) {
         // EXPERIMENT, timing only (wrong at the walls): every workgroup runs the lean interior body in 16-row bands
         constexpr int BY = 16;
@@ -560,7 +563,7 @@ void launch_jacobi_fused<float>(hipStream_t st, const SweepTune& tune, const Gri
         const int nzc = alt == 0 ? 5 : alt == 1 ? 6 : 4;
         const int zc_len = (g.D + nzc - 1) / nzc, nblk = nbands * nzc;
         hipLaunchKernelGGL((jacobi_fused_kernel<float, 3, 2, 8, 2, true, false, 2>), dim3(nblk), dim3(1024), 0, st, g, sc, src, rhs, dst, flags,
-                           b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk);
+                           b, a, inv_c, z_first, z_last, zc_len, zc_len, nbands, nblk, PeerPush());
         return;
     }
     if (levels == 3) {
@@ -586,11 +589,11 @@ void launch_jacobi_fused<float>(hipStream_t st, const SweepTune& tune, const Gri
 template <>
 void launch_jacobi_fused<double>(hipStream_t st, const SweepTune& tune, const GridDesc& g, const SlabCtx& sc, int,
                                  const double* src, const double* rhs, double* dst, const uint8_t* flags, int b, double a,
-                                 double inv_c, int z_first, int z_last, int plan, int second_first)
+                                 double inv_c, int z_first, int z_last, int plan, int second_first, const PeerPush* push)
 {
     if (plan < 0) plan = 0;
     const int alt = plan >> 3, shape = plan & 7;
-#define FS_F(NL, NX, NY, RY) launch_fused_v<double, NL, NX, NY, RY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first)
+#define FS_F(NL, NX, NY, RY) launch_fused_v<double, NL, NX, NY, RY>(st, tune, g, sc, src, rhs, dst, flags, b, a, inv_c, z_first, z_last, alt, second_first, push)
     // fp64: two sweeps per pass; rows up to 256 cells: 20-row bands; up to 512: 10-row bands (10 waves) or 8 (8 waves, 256 VGPRs)
     if (g.W <= 256) FS_F(2, 1, 10, 2);
     else if (shape == 1) FS_F(2, 2, 4, 2);

@@ -62,6 +62,10 @@ SCHEDULES = [
     (2, 32, "", "ipc", 5), (2, 32, "overlap=0", "ipc", 7), (2, 32, "overlap=1", "ipc", 7), (2, 32, "overlap=2", "ipc", 7),
     (3, 48, "overlap=2", "ipc", 8), (4, 64, "", "ipc", 8), (3, 48, "comm_cus=auto", "ipc", 7), (2, 32, "comm_cus=8,overlap=1", "ipc", 5),
     (2, 32, "split_density_solve=0", "ipc", 5), (4, 16, "", "ipc", 5),
+    # overlap=3, the push schedule: solver passes store their boundary planes straight into the neighbours' halo planes
+    # (three-sweep, two-sweep and single-sweep kernels: 8 iterations plan [3, 3, 2], 7 plan [3, 3, 1]; thin slabs too)
+    (2, 32, "overlap=3", "ipc", 8), (3, 48, "overlap=3", "ipc", 7), (4, 16, "overlap=3", "ipc", 5), (4, 64, "overlap=3", "ipc", 8),
+    (2, 32, "overlap=3", "shm", 5),          # a transport that cannot push runs schedule 3 as schedule 0
 ]
 
 
@@ -104,9 +108,9 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D, opts, transport, 
         syncs, waits, blocked, plan, cus = (int(v) for v in z["sched"])
         assert syncs == 0 and waits == 2 * steps + 1 and 0 <= blocked <= waits, (r, z["sched"])
         assert int(z["sched_end"][0]) == 0, (r, z["sched_end"])
-        want_plan = {"overlap=0": 0, "overlap=1": 1, "overlap=2": 2}
+        want_plan = {"overlap=0": 0, "overlap=1": 1, "overlap=2": 2, "overlap=3": 3}
         forced = [v for k, v in want_plan.items() if k in opts]
-        assert plan in (0, 1, 2) and (not forced or plan == forced[0]), (r, plan)
+        assert plan in (0, 1, 2, 3) and (not forced or plan == forced[0]), (r, plan)
         assert cus == (8 if "comm_cus=8" in opts else cus) and cus in (0, 8)
         plans = plans + [(plan, cus)] if r else [(plan, cus)]
     assert len(set(plans)) == 1, plans                      # "auto": every rank took the same decision
@@ -123,14 +127,24 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D, opts, transport, 
                           (24, 11, 32, 2, "fp32", "rbsor", ""), (20, 9, 12, 3, "fp64", "rbsor", ""),
                           (520, 7, 36, 3, "fp32", "jacobi", "two_sweep_kernel=fused"), (1000, 8, 24, 2, "fp32", "jacobi", "two_sweep_kernel=fused"),
                           (20, 12, 32, 2, "fp64", "jacobi", "two_sweep_kernel=fused"), (300, 9, 32, 2, "fp64", "jacobi", "two_sweep_kernel=fused"),
-                          (20, 12, 16, 2, "fp32", "jacobi", "two_sweep_kernel=pair"), (512, 8, 32, 2, "fp32", "jacobi", "")])
+                          (20, 12, 16, 2, "fp32", "jacobi", "two_sweep_kernel=pair"), (512, 8, 32, 2, "fp32", "jacobi", ""),
+                          # the push schedule (overlap=3, FSIPC) through every solver kernel: pair kernel on 1000-cell rows, fused
+                          # two-sweep kernel, fp64, three sweeps on 512-cell rows, and rbsor (its passes fall back to copies)
+                          (1000, 8, 24, 2, "fp32", "jacobi", "overlap=3,two_sweep_kernel=pair"), (520, 7, 36, 3, "fp32", "jacobi", "overlap=3,two_sweep_kernel=fused"),
+                          (300, 9, 32, 2, "fp64", "jacobi", "overlap=3"), (512, 8, 32, 2, "fp32", "jacobi", "overlap=3"),
+                          (24, 11, 32, 2, "fp32", "rbsor", "overlap=3")])
 def test_slabs_wide_rows_and_fp64(tmp_path, W, H, D, nranks, precision, solver, opts):
     """More than one 256-cell chunk per row, fp64 fields, each of the solver kernels on a slab (fp32 rows up to
     512 cells: three sweeps per pass across three-deep halos; the fused and the pair two-sweep kernel), and the
     optional red-black SOR solver (cell colour follows the global z, so slabs must agree with one GPU)."""
     args = [W, H, D, 7 if opts or W == 512 else 4, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision, solver, opts]
+    transport = "ipc" if "overlap=3" in opts else "shm"
+    if transport == "ipc":
+        ok, why = ipc_usable()
+        if not ok:
+            pytest.skip("FSIPC transport not usable on this box: " + why)
     ref_dir = run_ranks(str(tmp_path), 1, args)
-    par_dir = run_ranks(str(tmp_path), nranks, args)
+    par_dir = run_ranks(str(tmp_path), nranks, args, transport=transport)
     ref = np.load(os.path.join(ref_dir, "rank0.npz"))
     Dl = D // nranks
     u = np.uint64 if precision == "fp64" else np.uint32

@@ -57,7 +57,7 @@ if mode == "child":                                      # one rank of an ipc ru
     sys.exit(0)
 
 out = {"grid": [W, H, D], "ranks": P, "acc": acc, "transport": mode}
-for overlap in ("1", "2", "0", "auto"):
+for overlap in ("1", "2", "0", "3", "auto"):
     if mode == "ipc":
         idfile = "/tmp/fs_slab_time_%d.id" % os.getpid()
         open(idfile, "wb").write(F.comm_unique_id("ipc"))
