@@ -116,7 +116,23 @@ int fs_destroy(fs_sim* s);
  *   "wall_free"   "auto" (default) | "0" | "1": whether workgroups of the three-sweep kernel that touch no wall run its
  *                 wall-free second body (auto: when a launch has more than 256 workgroups);
  *   "sweep_ry" "sweep_zc" "sweep_blocks" "pair_zc" "pair_shape" "project_kernels" "fuse_advect"
- *   "overlap" ("0" | "1" default | "2") -- see csrc/kernels.h (SweepTune), csrc/fluidsim.cpp and tools/tune_*.py.
+ *                 -- see csrc/kernels.h (SweepTune), csrc/fluidsim.cpp and tools/tune_*.py.
+ * z-slab handles only (never change results either):
+ *   "overlap"     how a solver pass and the exchange of its boundary planes are scheduled: "0" the pass, then the exchange;
+ *                 "1" boundary planes first, their exchange beside the interior launch; "2" boundary launch + exchange on
+ *                 the communication stream beside the interior launch; "3" (FSIPC transport only, elsewhere = "0") the
+ *                 kernels store the boundary planes straight into the neighbours' halo planes; "auto" (default) times
+ *                 them once over the real transport, the slowest rank's time decides, every rank agrees.  Before the
+ *                 first solve.  fs_get_int "overlap_plan" / fs_get_float "overlap<k>_ms" report the choice and the times;
+ *   "comm_cus"    "0" (default) | N | "auto": CUs kept free of solver workgroups (CU-masked compute stream) for the
+ *                 transport's kernels; "auto" adds "8 free" to the timed candidates.  Before first use;
+ *   "split_density_solve" "1" (default) | "0": run half of the density solve (simulation.cpp:135) between the first
+ *                 projection and the velocity advection, so that the reach of each advection gather reaches the host
+ *                 without stalling the device (same passes, same order, same bits);
+ *   "debug_poison_gather" "1": fill the gathered advection source with NaN patterns before each gather (tests).
+ * fs_get_int also answers "local_depth" "z_offset" "halo_depth" "last_advect_reach" "pair_shape" "triple_plan"
+ * "two_sweep_fused" "mg_levels" and, for slab handles, "stream_syncs" (compute-stream synchronisations issued by slab
+ * steps; 0 on the step path) "reach_waits" "reach_waits_blocked" "reach_wait_us" "reach_hidden" "reach_exposed".
  */
 int fs_set_option(fs_sim* s, const char* key, const char* value);
 
@@ -232,7 +248,10 @@ int fs_surface_case_table(int config, int* edges);
 /* ---- multi-GPU z-slabs (one process per GPU; RCCL halo exchange over xGMI) -------- */
 
 /* Size of the opaque RCCL unique id; rank 0 fills it with fs_comm_unique_id and the
- * host layer broadcasts it to the other ranks (e.g. through torch.distributed). */
+ * host layer broadcasts it to the other ranks (e.g. through torch.distributed).  An id that starts with
+ * "FSIPC:" + a POSIX shared-memory name instead selects the stream-ordered device-to-device transport between rank
+ * processes of one host (csrc/ipc.h: hipIpc-mapped arrays, copy engines, device-side handshakes; ranks may share a
+ * GPU; at most 8 ranks); "FSSHM:" + name the host-staged synchronous development transport; "FSNULL:" none (timing). */
 #define FS_COMM_ID_BYTES 128
 int fs_comm_unique_id(void* id_out);
 /* Turns the handle into the owner of z-slab `rank` of `nranks` of the global grid given
