@@ -437,8 +437,9 @@ struct Comm {
         int mylo, myhi, ownlo, ownhi;
         window(rank, Dglobal, reach, mylo, myhi);
         owned(rank, Dglobal, ownlo, ownhi);
-        FS_HIPC(hipMemcpyAsync(d + (size_t)ownlo * plane, s + (ptrdiff_t)(ownlo - zoff) * (ptrdiff_t)plane,
-                               plane * (size_t)(ownhi - ownlo + 1), hipMemcpyDeviceToDevice, st));
+        if (d + (size_t)ownlo * plane != s + (ptrdiff_t)(ownlo - zoff) * (ptrdiff_t)plane)   // (in place: the planes are where they belong)
+            FS_HIPC(hipMemcpyAsync(d + (size_t)ownlo * plane, s + (ptrdiff_t)(ownlo - zoff) * (ptrdiff_t)plane,
+                                   plane * (size_t)(ownhi - ownlo + 1), hipMemcpyDeviceToDevice, st));
         if (null_transport) return 0;
         if (shm) {
             if (shm_ready(g, Dglobal)) return -1;

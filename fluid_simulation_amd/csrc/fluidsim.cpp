@@ -99,6 +99,7 @@ struct fs_sim {
     float omega = 1.0f;          // relaxation factor of solver=rbsor
     int plan_two = -2, plan_three = -2;   // "launch_plans": replay these instead of timing (-2: not set)
     int mg_cycles = 4, mg_pre = 1, mg_post = 1, mg_coarse = 30;   // solver=mg: V-cycles per pressure solve, smoothing steps, coarsest-level iterations
+    int mg_min_planes = 4;       // z-slabs: a coarse level stays distributed while every rank keeps at least this many of its planes
     std::string dump_dir = "data";
     int dump_every = 1;
     unsigned voxel_seed = 1;
@@ -950,15 +951,46 @@ struct Engine : EngineBase {
     // kernel (its red-black instantiation is 1.6x slower and smooths no better here), the coarse levels live in
     // multigrid.hip.  Single GPU.
     int multigrid_levels() const override { return mg.levels(); }
+    static constexpr int SLOT_MG = NPOOL + 4;            // FSIPC export slot of the multigrid level arrays
+    // the transport's part in the coarse levels of a slab run (multigrid.h): one-plane halo refreshes of distributed levels,
+    // all-gathers at the seam to the levels every rank holds whole
+    fs::MgHooks<T> mg_hooks()
+    {
+        fs::MgHooks<T> h;
+        h.halo = [this](const fs::MgLevel<T>& l, T* a) -> int {
+            fs::GridDesc lg = g;
+            lg.sz = l.sz; lg.sy = l.sy; lg.D = l.D; lg.W = l.W; lg.H = l.H;
+            return comm_op([&](hipStream_t st) { return S->comm.exchange_halo(st, a, lg, sizeof(T), l.D * S->comm.nranks, 1); },
+                           "halo exchange of a multigrid level");
+        };
+        h.gather = [this](const fs::MgLevel<T>& l, T* a, int dl, int zoff) -> int {
+            fs::GridDesc lg = g;
+            lg.sz = l.sz; lg.sy = l.sy; lg.D = dl; lg.W = l.W; lg.H = l.H;
+            return comm_op([&](hipStream_t st) { return S->comm.all_gather_planes(st, a + (long)zoff * l.sz, a, lg, l.D, sizeof(T)); },
+                           "all-gather of a multigrid level");
+        };
+        return h;
+    }
     int multigrid_solve(int field, int prev, int* result)
     {
-        if (S->comm.active()) return fail(FS_EINVAL, "solver=mg is single-GPU (z-slab runs use jacobi or rbsor)");
         if (S->mg_cycles > 0 && !fs::pair_supported<T>(S->tune, g, sc))
             return fail(FS_EINVAL, "solver=mg needs rows of at most 1024 cells and sweep_fuse >= 2");
+        const bool slabs = S->comm.active();
+        fs::MgHooks<T> hooks;
+        if (slabs) hooks = mg_hooks();
         if (!mg_current) {
             ScopedSpan sp(S, FAM_MG);
-            hipError_t e = mg.build(S->stream, g, flags);
-            if (e != hipSuccess) return fail(FS_EHIP, "multigrid levels: %s", hipGetErrorString(e));
+            int brc = mg.build(S->stream, g, sc, flags, slabs ? S->comm.nranks : 1, slabs ? S->comm.rank : 0, S->mg_min_planes,
+                               slabs ? &hooks : nullptr);
+            if (brc == -1) {
+                // a fresh allocation on a slab rank: the neighbours (halo planes) and, at the seam, all ranks write into it
+                if (S->comm.register_buffer(SLOT_MG, mg.pool, mg.pool_elems * sizeof(T), true))
+                    return fail(FS_ECOMM, "exporting the multigrid levels: %s", S->comm.last_error());
+                brc = mg.build(S->stream, g, sc, flags, S->comm.nranks, S->comm.rank, S->mg_min_planes, &hooks);
+            }
+            if (brc == 2) return fail(FS_EINVAL, "solver=mg on z-slabs needs an even number of planes per rank (%d)", g.D);
+            if (brc == 3) return FS_ECOMM;               // the hook has set the message
+            if (brc) return fail(FS_EHIP, "multigrid levels: %s", hipGetErrorString(hipGetLastError()));
             mg_current = true;
         }
         const int own = slot[field], rhs = slot[prev];
@@ -982,8 +1014,13 @@ struct Engine : EngineBase {
             if ((rc = smooth(S->mg_pre))) return rc;
             {
                 ScopedSpan sp(S, FAM_MG);
-                mg.coarse_correction(S->stream, g, sc, flags, arr[cur], arr[rhs], S->mg_pre, S->mg_post, S->mg_coarse);
+                const int crc = mg.coarse_correction(S->stream, g, sc, flags, arr[cur], arr[rhs], S->mg_pre, S->mg_post, S->mg_coarse,
+                                                     slabs ? &hooks : nullptr);
+                if (crc == 3) return FS_ECOMM;
+                if (crc) return fail(FS_EHIP, "multigrid cycle: %s", hipGetErrorString(hipGetLastError()));
             }
+            // the correction changed this rank's planes of p: the neighbours' copies of its boundary planes are stale
+            if (slabs && (rc = halo(arr[cur]))) return rc;
             if ((rc = smooth(S->mg_post))) return rc;
         }
         if (cur == own) held[own] = true;                 // adopt() releases it again
@@ -1777,6 +1814,10 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         const int n = atoi(value);
         if (n < (k == "mg_cycles" ? 0 : 1) || n > 1000) return fail(FS_EINVAL, "%s out of range", key);
         (k == "mg_cycles" ? s->mg_cycles : k == "mg_pre" ? s->mg_pre : k == "mg_post" ? s->mg_post : s->mg_coarse) = n;
+    } else if (k == "mg_min_planes") {
+        const int n = atoi(value);
+        if (n < 1 || n > 1024) return fail(FS_EINVAL, "mg_min_planes: 1 .. 1024");
+        s->mg_min_planes = n;
     } else if (k == "launch_plans") {
         int two = -2, three = -2;
         if (sscanf(value, "%d,%d", &two, &three) != 2 || two < -1 || three < -1 || two > 127 || three > 31)

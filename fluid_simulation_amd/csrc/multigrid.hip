@@ -23,35 +23,38 @@ __device__ __forceinline__ long lat(const MgLevel<T>& l, int x, int y, int z)
 }
 
 // ---- level-0 coefficients from the flag bytes (never stored) --------------------------------
-__device__ __forceinline__ bool in_range(const GridDesc& g, int x, int y, int z)
+// z-slab runs: "in range" follows the GLOBAL depth -- plane z of a slab is global plane sc.zoff + z, and the halo planes of
+// the flag bytes hold the neighbouring slabs' cells (the flag build covers them, kernels.hip)
+__device__ __forceinline__ bool in_range(const GridDesc& g, const SlabCtx& sc, int x, int y, int z)
 {
-    return x >= 1 && x <= g.W && y >= 1 && y <= g.H && z >= 1 && z <= g.D;
+    const int zg = z + sc.zoff;
+    return x >= 1 && x <= g.W && y >= 1 && y <= g.H && zg >= 1 && zg <= sc.Dglobal;
 }
-__device__ __forceinline__ bool fluid0(const GridDesc& g, const uint8_t* flags, int x, int y, int z)
+__device__ __forceinline__ bool fluid0(const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, int x, int y, int z)
 {
-    return in_range(g, x, y, z) && !(flags[cell(g, x, y, z)] & F_SOLID);
+    return in_range(g, sc, x, y, z) && !(flags[cell(g, x, y, z)] & F_SOLID);
 }
-__device__ __forceinline__ int solid0(const GridDesc& g, const uint8_t* flags, int x, int y, int z)
+__device__ __forceinline__ int solid0(const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, int x, int y, int z)
 {
-    return (in_range(g, x, y, z) && (flags[cell(g, x, y, z)] & F_SOLID)) ? 1 : 0;
+    return (in_range(g, sc, x, y, z) && (flags[cell(g, x, y, z)] & F_SOLID)) ? 1 : 0;
 }
 template <class T>
-__device__ __forceinline__ T w0(const GridDesc& g, const uint8_t* flags, int x, int y, int z, int axis)
+__device__ __forceinline__ T w0(const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, int x, int y, int z, int axis)
 {
     const int xm = x - (axis == 0), ym = y - (axis == 1), zm = z - (axis == 2);
-    return (fluid0(g, flags, x, y, z) && fluid0(g, flags, xm, ym, zm)) ? (T)1 : (T)0;
+    return (fluid0(g, sc, flags, x, y, z) && fluid0(g, sc, flags, xm, ym, zm)) ? (T)1 : (T)0;
 }
 template <class T>
-__device__ __forceinline__ T d0(const GridDesc& g, const uint8_t* flags, int x, int y, int z)
+__device__ __forceinline__ T d0(const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, int x, int y, int z)
 {
-    if (!fluid0(g, flags, x, y, z)) return (T)0;
-    return (T)(solid0(g, flags, x + 1, y, z) + solid0(g, flags, x - 1, y, z) + solid0(g, flags, x, y + 1, z) +
-               solid0(g, flags, x, y - 1, z) + solid0(g, flags, x, y, z + 1) + solid0(g, flags, x, y, z - 1));
+    if (!fluid0(g, sc, flags, x, y, z)) return (T)0;
+    return (T)(solid0(g, sc, flags, x + 1, y, z) + solid0(g, sc, flags, x - 1, y, z) + solid0(g, sc, flags, x, y + 1, z) +
+               solid0(g, sc, flags, x, y - 1, z) + solid0(g, sc, flags, x, y, z + 1) + solid0(g, sc, flags, x, y, z - 1));
 }
 
 // Coefficients of level c from the level below: stored level f, or (FROM0) level 0's flag bytes.
 template <class T, bool FROM0>
-__global__ __launch_bounds__(256) void mg_coarsen_kernel(GridDesc g, const uint8_t* __restrict__ flags, MgLevel<T> f, MgLevel<T> c)
+__global__ __launch_bounds__(256) void mg_coarsen_kernel(GridDesc g, SlabCtx sc, const uint8_t* __restrict__ flags, MgLevel<T> f, MgLevel<T> c)
 {
     const int X = 1 + blockIdx.x * 64 + threadIdx.x, Y = 1 + blockIdx.y * 4 + threadIdx.y, Z = 1 + blockIdx.z;
     if (X > c.W + 1 || Y > c.H + 1 || Z > c.D + 1) return;
@@ -59,11 +62,11 @@ __global__ __launch_bounds__(256) void mg_coarsen_kernel(GridDesc g, const uint8
     const int x = 2 * X - 1, y = 2 * Y - 1, z = 2 * Z - 1;      // first child
     const T q = (T)0.25, hf = (T)0.5;
     auto FW = [&](int axis, int xx, int yy, int zz) -> T {
-        if constexpr (FROM0) return w0<T>(g, flags, xx, yy, zz, axis);
+        if constexpr (FROM0) return w0<T>(g, sc, flags, xx, yy, zz, axis);
         else return (axis == 0 ? f.wx : axis == 1 ? f.wy : f.wz)[lat(f, xx, yy, zz)];
     };
     auto FD = [&](int xx, int yy, int zz) -> T {
-        if constexpr (FROM0) return d0<T>(g, flags, xx, yy, zz);
+        if constexpr (FROM0) return d0<T>(g, sc, flags, xx, yy, zz);
         else return f.d[lat(f, xx, yy, zz)];
     };
     if (Y <= c.H && Z <= c.D) c.wx[C] = q * (((FW(0, x, y, z) + FW(0, x, y + 1, z)) + FW(0, x, y, z + 1)) + FW(0, x, y + 1, z + 1));
@@ -107,7 +110,7 @@ template <class T>
 __global__ __launch_bounds__(256) void mg_smooth_kernel(MgLevel<T> l, int colour)
 {
     const int y = 1 + blockIdx.y * 4 + threadIdx.y, z = 1 + blockIdx.z;
-    const int x = 1 + 2 * (blockIdx.x * 64 + threadIdx.x) + (((y + z + colour) & 1) ? 0 : 1);
+    const int x = 1 + 2 * (blockIdx.x * 64 + threadIdx.x) + (((y + z + l.zoff + colour) & 1) ? 0 : 1);   // colour by global z
     if (x > l.W || y > l.H) return;
     const long c = lat(l, x, y, z);
     if (l.reg[c]) {
@@ -228,7 +231,9 @@ __device__ __forceinline__ T interp(const MgLevel<T>& c, int x, int y, int z)
     const int X = (x + 1) >> 1, Y = (y + 1) >> 1, Z = (z + 1) >> 1;
     const int Xn = min(max((x & 1) ? X - 1 : X + 1, 1), c.W);
     const int Yn = min(max((y & 1) ? Y - 1 : Y + 1, 1), c.H);
-    const int Zn = min(max((z & 1) ? Z - 1 : Z + 1, 1), c.D);
+    // (z-slabs: the fine level's plane offset is even, so local parity is global parity; beyond a slab side without a
+    // physical wall lies the neighbour's plane, held in the halo plane of e -- no clamp there)
+    const int Zn = min(max((z & 1) ? Z - 1 : Z + 1, c.lo_wall ? 1 : 0), c.hi_wall ? c.D : c.D + 1);
     const T a = (T)0.75, q = (T)0.25;
     const T* e = c.e;
     const T x00 = a * e[lat(c, X, Y, Z)] + q * e[lat(c, Xn, Y, Z)];
@@ -262,7 +267,8 @@ __global__ __launch_bounds__(256) void mg_prolong0_kernel(MgLevel<T> c, GridDesc
     const int X = (x0 + 1) >> 1;
     // coarse columns of the four cells: own (X, X, X+1, X+1), neighbour (X-1, X+1, X, X+2), clamped at the walls
     const int col[4] = { max(X - 1, 1), X, min(X + 1, c.W), min(X + 2, c.W) };
-    const int Yc[3] = { max(Y - 1, 1), Y, min(Y + 1, c.H) }, Zc[3] = { max(Z - 1, 1), Z, min(Z + 1, c.D) };
+    const int Yc[3] = { max(Y - 1, 1), Y, min(Y + 1, c.H) };
+    const int Zc[3] = { max(Z - 1, c.lo_wall ? 1 : 0), Z, min(Z + 1, c.hi_wall ? c.D : c.D + 1) };   // halo plane beyond a slab side
     T R[3][3][4];                                         // [z][y][column]
 #pragma unroll
     for (int zi = 0; zi < 3; ++zi)
@@ -404,33 +410,72 @@ void Multigrid<T>::release()
     if (reg_pool) hipFree(reg_pool);
     pool = nullptr;
     reg_pool = nullptr;
+    pool_elems = 0;
     lv.clear();
     W0 = H0 = D0 = 0;
 }
 
+// This rank's planes of replicated level l as a slab: the pointers are shifted so that plane z of the view is global plane
+// zoff + z; the planes beside it are the neighbours' (the array holds the whole level), so the view needs no halo exchange.
 template <class T>
-hipError_t Multigrid<T>::build(hipStream_t st, const GridDesc& g, const uint8_t* flags)
+MgLevel<T> Multigrid<T>::slab_view(int l, int fine_zoff, int fine_D, const SlabCtx& sc) const
 {
-    if (g.W != W0 || g.H != H0 || g.D != D0 || lv.empty()) {
+    MgLevel<T> v = lv[l];
+    v.zoff = fine_zoff / 2;
+    v.D = fine_D / 2;
+    v.lo_wall = sc.lo_wall;
+    v.hi_wall = sc.hi_wall;
+    const long shift = (long)v.zoff * v.sz;
+    for (T** a : { &v.wx, &v.wy, &v.wz, &v.d, &v.dg, &v.e, &v.b }) *a += shift;
+    v.reg += shift;
+    return v;
+}
+
+template <class T>
+int Multigrid<T>::build(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, int nranks_, int rank_,
+                        int min_planes, const MgHooks<T>* hooks)
+{
+    const int Dg = sc.Dglobal;
+    if (g.W != W0 || g.H != H0 || g.D != D0 || nranks_ != nranks || rank_ != rank || lv.empty()) {
         release();
         W0 = g.W; H0 = g.H; D0 = g.D;
-        lv.push_back(MgLevel<T>{g.W, g.H, g.D, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
-        int W = g.W, H = g.H, D = g.D;
+        nranks = nranks_;
+        rank = rank_;
+        MgLevel<T> l0{};
+        l0.W = g.W; l0.H = g.H; l0.D = g.D;
+        lv.push_back(l0);
+        // the hierarchy is that of the GLOBAL grid (a slab run must coarsen exactly like the same run on one GPU)
+        int W = g.W, H = g.H, D = Dg;
+        first_repl = 1;
+        bool dist = nranks > 1;                           // one GPU: every level is held whole
         size_t total = 0;
         while (W % 2 == 0 && H % 2 == 0 && D % 2 == 0 && W / 2 >= MG_MIN_DIM && H / 2 >= MG_MIN_DIM && D / 2 >= MG_MIN_DIM) {
             W /= 2; H /= 2; D /= 2;
             MgLevel<T> l{};
-            l.W = W; l.H = H; l.D = D;
+            l.W = W; l.H = H;
+            // a level stays distributed while every rank keeps at least min_planes planes of it
+            dist = dist && D % nranks == 0 && D / nranks >= (min_planes > 1 ? min_planes : 1);
+            if (dist) {
+                l.D = D / nranks;
+                l.zoff = rank * l.D;
+                l.lo_wall = sc.lo_wall;
+                l.hi_wall = sc.hi_wall;
+                first_repl = (int)lv.size() + 1;
+            } else {
+                l.D = D;
+            }
             l.sy = W + 2;
             l.sz = l.sy * (H + 2);
-            l.n = l.sz * (D + 2);
+            l.n = l.sz * (l.D + 2);
             total += 7 * (size_t)l.n;
             lv.push_back(l);
         }
+        if (nranks > 1 && lv.size() > 1 && (g.D % 2) != 0) { release(); return 2; }   // children of a coarse cell must be one rank's
         if (total) {
             hipError_t e = hipMalloc((void**)&pool, total * sizeof(T));
             if (e == hipSuccess) e = hipMalloc((void**)&reg_pool, total / 7);
-            if (e != hipSuccess) { release(); return e; }
+            if (e != hipSuccess) { release(); return 1; }
+            pool_elems = total;
             T* q = pool;
             uint8_t* rq = reg_pool;
             for (size_t i = 1; i < lv.size(); ++i) {
@@ -441,42 +486,51 @@ hipError_t Multigrid<T>::build(hipStream_t st, const GridDesc& g, const uint8_t*
                 rq += l.n;
             }
         }
+        if (nranks > 1) return -1;                       // fresh allocation: the caller exports it to its peers, then calls again
     }
     if (pool) {
-        size_t total = 0;
-        for (size_t i = 1; i < lv.size(); ++i) total += 7 * (size_t)lv[i].n;
-        hipError_t e = hipMemsetAsync(pool, 0, total * sizeof(T), st);     // ghosts, dead cells and wall faces stay 0
-        if (e == hipSuccess) e = hipMemsetAsync(reg_pool, 0, total / 7, st);
-        if (e != hipSuccess) return e;
+        hipError_t e = hipMemsetAsync(pool, 0, pool_elems * sizeof(T), st);     // ghosts, dead cells and wall faces stay 0
+        if (e == hipSuccess) e = hipMemsetAsync(reg_pool, 0, pool_elems / 7, st);
+        if (e != hipSuccess) return 1;
     }
-    for (size_t i = 1; i < lv.size(); ++i) {
-        MgLevel<T>& c = lv[i];
+    const int nl = levels();
+    for (int i = 1; i < nl; ++i) {
+        // coefficients of level i from level i-1.  The first replicated level below a distributed one: every rank computes
+        // its planes (as a slab view), then the four coefficient arrays are gathered.
+        const bool seam = nranks > 1 && i == first_repl;
+        const int fz = (i == 1) ? sc.zoff : lv[i - 1].zoff, fD = (i == 1) ? g.D : lv[i - 1].D;
+        MgLevel<T> c = seam ? slab_view(i, fz, fD, sc) : lv[i];
         if (i == 1)
-            hipLaunchKernelGGL((mg_coarsen_kernel<T, true>), grd(c.W + 1, c.H + 1, c.D + 1), blk(), 0, st, g, flags, lv[0], c);
+            hipLaunchKernelGGL((mg_coarsen_kernel<T, true>), grd(c.W + 1, c.H + 1, c.D + 1), blk(), 0, st, g, sc, flags, lv[0], c);
         else
-            hipLaunchKernelGGL((mg_coarsen_kernel<T, false>), grd(c.W + 1, c.H + 1, c.D + 1), blk(), 0, st, g, flags, lv[i - 1], c);
-        hipLaunchKernelGGL((mg_diag_kernel<T>), grd(c.W, c.H, c.D), blk(), 0, st, c);
+            hipLaunchKernelGGL((mg_coarsen_kernel<T, false>), grd(c.W + 1, c.H + 1, c.D + 1), blk(), 0, st, g, sc, flags, lv[i - 1], c);
+        if (seam) {
+            if (!hooks) return 1;
+            for (T* a : { lv[i].wx, lv[i].wy, lv[i].wz, lv[i].d })
+                if (hooks->gather(lv[i], a, c.D, c.zoff)) return 3;
+        }
+        hipLaunchKernelGGL((mg_diag_kernel<T>), grd(lv[i].W, lv[i].H, lv[i].D), blk(), 0, st, lv[i]);
     }
-    return hipGetLastError();
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// Levels first .. coarsest, all held whole by this rank: pre-smooth and restrict on the way down, coarse_iters on the
+// coarsest, prolong and post-smooth on the way up; the levels of at most BOTTOM_CELLS cells as one single-workgroup launch.
 template <class T>
-void Multigrid<T>::coarse_correction(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, T* p, const T* rhs,
-                                     int pre, int post, int coarse_iters)
+void Multigrid<T>::vcycle_replicated(hipStream_t st, int first, int pre, int post, int coarse_iters)
 {
     const int nl = levels();
-    if (nl < 2) return;
+    if (first >= nl) return;
     auto smooth = [&](MgLevel<T>& l, int n) {
         for (int it = 0; it < n; ++it)
             for (int colour = 0; colour < 2; ++colour)
                 hipLaunchKernelGGL((mg_smooth_kernel<T>), grd((l.W + 1) / 2, l.H, l.D), blk(), 0, st, l, colour);
     };
-    hipLaunchKernelGGL((mg_restrict0_kernel<T>), grd((g.W + 3) / 4, lv[1].H, lv[1].D), blk(), 0, st, g, flags, p, rhs, lv[1]);
     int lb = nl;                                          // first level of the single-workgroup bottom
-    for (int l = 1; l < nl; ++l)
+    for (int l = first; l < nl; ++l)
         if ((long)lv[l].W * lv[l].H * lv[l].D <= BOTTOM_CELLS && nl - l <= BOTTOM_MAX) { lb = l; break; }
     const int top = lb < nl - 1 ? lb : nl - 1;            // the level the launches below stop at
-    for (int l = 1; l < top; ++l) {                       // down
+    for (int l = first; l < top; ++l) {                   // down
         smooth(lv[l], pre);
         hipLaunchKernelGGL((mg_restrict_kernel<T>), grd(lv[l + 1].W, lv[l + 1].H, lv[l + 1].D), blk(), 0, st, lv[l], lv[l + 1]);
     }
@@ -489,11 +543,80 @@ void Multigrid<T>::coarse_correction(hipStream_t st, const GridDesc& g, const Sl
     } else {
         smooth(lv[nl - 1], coarse_iters);
     }
-    for (int l = top - 1; l >= 1; --l) {                  // up
+    for (int l = top - 1; l >= first; --l) {              // up
         hipLaunchKernelGGL((mg_prolong_kernel<T>), grd(lv[l].W, lv[l].H, lv[l].D), blk(), 0, st, lv[l + 1], lv[l]);
         smooth(lv[l], post);
     }
-    hipLaunchKernelGGL((mg_prolong0_kernel<T>), grd((g.W + 3) / 4, lv[1].H, lv[1].D), blk(), 0, st, lv[1], g, sc, flags, p);
+}
+
+template <class T>
+int Multigrid<T>::coarse_correction(hipStream_t st, const GridDesc& g, const SlabCtx& sc, const uint8_t* flags, T* p, const T* rhs,
+                                    int pre, int post, int coarse_iters, const MgHooks<T>* hooks)
+{
+    const int nl = levels();
+    if (nl < 2) return 0;
+    if (nranks == 1) {
+        hipLaunchKernelGGL((mg_restrict0_kernel<T>), grd((g.W + 3) / 4, lv[1].H, lv[1].D), blk(), 0, st, g, flags, p, rhs, lv[1]);
+        vcycle_replicated(st, 1, pre, post, coarse_iters);
+        hipLaunchKernelGGL((mg_prolong0_kernel<T>), grd((g.W + 3) / 4, lv[1].H, lv[1].D), blk(), 0, st, lv[1], g, sc, flags, p);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
+    // ---- z-slabs: the same operations in the same order; what differs is where a level lives
+    if (!hooks) return 1;
+    const int fr = first_repl;                             // levels 1 .. fr-1 distributed, fr .. nl-1 held whole by every rank
+    auto fine_zoff = [&](int l) { return l == 0 ? sc.zoff : lv[l].zoff; };
+    auto fine_D = [&](int l) { return l == 0 ? g.D : lv[l].D; };
+    // level l as the level above it sees it: itself if distributed, else this rank's planes of the replicated array
+    auto as_child_of = [&](int l) { return (l == fr) ? slab_view(l, fine_zoff(l - 1), fine_D(l - 1), sc) : lv[l]; };
+    // after a restriction into level l: a distributed level's halo planes of e must be the neighbours' zeros; a replicated
+    // level needs everybody's planes of b and a zero e everywhere
+    auto after_restrict = [&](int l, const MgLevel<T>& written) -> int {
+        if (l == fr) {
+            if (hooks->gather(lv[l], lv[l].b, written.D, written.zoff)) return 3;
+            if (hipMemsetAsync(lv[l].e, 0, (size_t)lv[l].n * sizeof(T), st) != hipSuccess) return 1;
+        } else {
+            if (hipMemsetAsync(lv[l].e, 0, (size_t)lv[l].sz * sizeof(T), st) != hipSuccess) return 1;
+            if (hipMemsetAsync(lv[l].e + (long)(lv[l].D + 1) * lv[l].sz, 0, (size_t)lv[l].sz * sizeof(T), st) != hipSuccess) return 1;
+        }
+        return 0;
+    };
+    // red-black smoothing of a distributed level: each colour reads the other colour's cells of the neighbours' boundary planes
+    auto smooth_dist = [&](MgLevel<T>& l, int n) -> int {
+        for (int it = 0; it < n; ++it)
+            for (int colour = 0; colour < 2; ++colour) {
+                hipLaunchKernelGGL((mg_smooth_kernel<T>), grd((l.W + 1) / 2, l.H, l.D), blk(), 0, st, l, colour);
+                if (hooks->halo(l, l.e)) return 3;
+            }
+        return 0;
+    };
+    int rc;
+    {
+        MgLevel<T> c1 = as_child_of(1);
+        hipLaunchKernelGGL((mg_restrict0_kernel<T>), grd((g.W + 3) / 4, c1.H, c1.D), blk(), 0, st, g, flags, p, rhs, c1);
+        if ((rc = after_restrict(1, c1))) return rc;
+    }
+    for (int l = 1; l < fr; ++l) {                         // down the distributed levels
+        if (l == nl - 1) {                                 // the coarsest level of all is still distributed
+            if ((rc = smooth_dist(lv[l], coarse_iters))) return rc;
+            break;
+        }
+        if ((rc = smooth_dist(lv[l], pre))) return rc;
+        MgLevel<T> c = as_child_of(l + 1);
+        hipLaunchKernelGGL((mg_restrict_kernel<T>), grd(c.W, c.H, c.D), blk(), 0, st, lv[l], c);
+        if ((rc = after_restrict(l + 1, c))) return rc;
+    }
+    vcycle_replicated(st, fr, pre, post, coarse_iters);   // nothing to communicate below
+    for (int l = (fr < nl ? fr : nl - 1) - 1; l >= 1; --l) {   // up the distributed levels
+        MgLevel<T> c = as_child_of(l + 1);
+        hipLaunchKernelGGL((mg_prolong_kernel<T>), grd(lv[l].W, lv[l].H, lv[l].D), blk(), 0, st, c, lv[l]);
+        if (hooks->halo(lv[l], lv[l].e)) return 3;
+        if ((rc = smooth_dist(lv[l], post))) return rc;
+    }
+    {
+        MgLevel<T> c1 = as_child_of(1);
+        hipLaunchKernelGGL((mg_prolong0_kernel<T>), grd((g.W + 3) / 4, c1.H, c1.D), blk(), 0, st, c1, g, sc, flags, p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 template struct Multigrid<float>;

@@ -85,8 +85,10 @@ def test_multigrid_solves_the_reference_pressure_equation(F, shape):
     assert res["jacobi"] > 0.1, res
 
 
-def test_multigrid_follows_obstacle_edits_and_is_refused_on_slabs(F, oracle_mod):
-    """The coarse operators are rebuilt when the obstacle field changes between steps; a z-slab rank refuses the mode."""
+def test_multigrid_follows_obstacle_edits_and_odd_slabs_are_refused(F, oracle_mod):
+    """The coarse operators are rebuilt when the obstacle field changes between steps.  On z-slabs the mode runs
+    (tests/test_gpu_slabs.py::test_slabs_multigrid_matches_single_gpu) unless a rank would hold an odd number of planes:
+    the eight children of a coarse cell must be one rank's."""
     O = oracle_mod
     W, H, D = 32, 16, 16
     sim = F.Simulation(W, H, D, 1, acc=4, solver="mg", quiet=1)
@@ -98,7 +100,7 @@ def test_multigrid_follows_obstacle_edits_and_is_refused_on_slabs(F, oracle_mod)
         ora.run_one()
     for f in range(11):
         assert bits_equal(sim.get(f), ora.get(f)), F.FIELD_NAMES[f]
-    slab = F.Simulation(W, H, D, 1, acc=4, solver="mg", quiet=1)
+    slab = F.Simulation(W, H, 18, 1, acc=4, solver="mg", quiet=1)        # 9 planes per rank
     slab.comm_init(0, 2, b"FSNULL:".ljust(128, b"\0"))
     with pytest.raises(F.FluidsimError):
         slab.run_one()

@@ -25,11 +25,12 @@ rank = int(sys.argv[5]) if len(sys.argv) > 5 else P // 2
 acc = int(sys.argv[6]) if len(sys.argv) > 6 else 80
 steps = int(sys.argv[7]) if len(sys.argv) > 7 else 3
 mode = sys.argv[8] if len(sys.argv) > 8 else "null"
-FAMS = ("sweep", "sweep_pair", "sweep_triple", "divergence", "gradient", "advect", "comm", "misc")
+FAMS = ("sweep", "sweep_pair", "sweep_triple", "divergence", "gradient", "advect", "comm", "misc", "multigrid")
 
 
 def one_rank(uid, overlap):
-    sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0, profile=1, overlap=overlap)
+    sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0, profile=1, overlap=overlap,
+                       solver=os.environ.get("FS_SOLVER", "jacobi"))      # FS_SOLVER=mg: the multigrid pressure solve on slabs
     if P > 1:
         sim.comm_init(rank, P, uid)
     sim.addObstacle(W // 3, H // 2, D // 2)              # every rank issues the same call (rank-symmetric bookkeeping)
@@ -56,7 +57,7 @@ if mode == "child":                                      # one rank of an ipc ru
     print(json.dumps(one_rank(uid, sys.argv[10])))
     sys.exit(0)
 
-out = {"grid": [W, H, D], "ranks": P, "acc": acc, "transport": mode}
+out = {"grid": [W, H, D], "ranks": P, "acc": acc, "transport": mode, "solver": os.environ.get("FS_SOLVER", "jacobi")}
 for overlap in ("1", "2", "0", "3", "auto"):
     if mode == "ipc":
         idfile = "/tmp/fs_slab_time_%d.id" % os.getpid()
