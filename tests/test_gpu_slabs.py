@@ -172,7 +172,8 @@ def test_depth_must_divide(tmp_path):
 
 def _soak_cases():
     """Seeded random slab configurations: rank counts, slab depths down to the halo depth, row widths around the
-    kernels' limits (256, 512, 1024 cells), both precisions, every overlap mode and two-sweep kernel.  FS_SOAK=N draws N
+    kernels' limits (256, 512, 1024 cells), both precisions, every communication schedule (incl. the push schedule and
+    "auto"), both development transports, CU masks and two-sweep kernels.  FS_SOAK=N draws N
     cases instead of the default handful (development soak; every case is a full bit-exact comparison)."""
     n = int(os.environ.get("FS_SOAK", "6"))
     rng = np.random.default_rng(20261005)
@@ -185,18 +186,25 @@ def _soak_cases():
         H = int(rng.integers(7, 26))
         acc = int(rng.integers(1, 10))
         prec = str(rng.choice(["fp32", "fp32", "fp64"]))
-        opts = ["overlap=%d" % int(rng.integers(0, 3)), "two_sweep_kernel=%s" % rng.choice(["auto", "pair", "fused"])]
+        opts = ["overlap=%s" % rng.choice(["0", "1", "2", "3", "auto"]), "two_sweep_kernel=%s" % rng.choice(["auto", "pair", "fused"])]
         if rng.random() < 0.25:
             opts.append("sweep_fuse=2")
-        cases.append((i, W, H, dl * nranks, nranks, acc, prec, ",".join(opts)))
+        if rng.random() < 0.2:
+            opts.append("comm_cus=8")
+        transport = str(rng.choice(["ipc", "ipc", "shm"]))
+        cases.append((i, W, H, dl * nranks, nranks, acc, prec, ",".join(opts), transport))
     return cases
 
 
-@pytest.mark.parametrize("case,W,H,D,nranks,acc,precision,opts", _soak_cases())
-def test_random_slab_configurations_match_single_gpu(tmp_path, case, W, H, D, nranks, acc, precision, opts):
+@pytest.mark.parametrize("case,W,H,D,nranks,acc,precision,opts,transport", _soak_cases())
+def test_random_slab_configurations_match_single_gpu(tmp_path, case, W, H, D, nranks, acc, precision, opts, transport):
+    if transport == "ipc":
+        ok, why = ipc_usable()
+        if not ok:
+            pytest.skip("FSIPC transport not usable on this box: " + why)
     args = [W, H, D, acc, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision, "jacobi", opts]
     ref_dir = run_ranks(str(tmp_path), 1, args)
-    par_dir = run_ranks(str(tmp_path), nranks, args)
+    par_dir = run_ranks(str(tmp_path), nranks, args, transport=transport)
     ref = np.load(os.path.join(ref_dir, "rank0.npz"))
     Dl = D // nranks
     u = np.uint64 if precision == "fp64" else np.uint32
