@@ -67,7 +67,15 @@ int main(int argc, char** argv)
         pid_t kids[2];
         for (int r = 0; r < 2; ++r) {
             kids[r] = fork();
-            if (kids[r] == 0) return slab_rank(r, id, ascii, dumpdir);     // return (not _exit): the sanitizers' exit checks run
+            if (kids[r] == 0) {
+                // _exit, not return: in a forked child the HIP runtime's own exit handler trips a CHECK inside the ASan runtime
+                // (sanitizer_allocator_device.h, "dev_runtime_unloaded_") after everything of ours has run clean; address
+                // and UB findings are reported where they happen, not at exit (leak checking is off under HIP anyway)
+                const int rc = slab_rank(r, id, ascii, dumpdir);
+                fflush(stdout);
+                fflush(stderr);
+                _exit(rc);
+            }
         }
         int bad = 0;
         for (int r = 0; r < 2; ++r) {
