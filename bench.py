@@ -153,7 +153,7 @@ def cpu_baseline(budget_s=10.0):
     return out
 
 
-def slab_parity_check(F, fsdist, dist, rank, world, transport, ctl_device):
+def slab_parity_check(F, fsdist, dist, rank, world, transport, ctl_device, schedules=None):
     """N>1 only, before the timed run: every rank runs a small tunnel whole on its own GPU, then as its z-slab of
     a world-wide run over the real transport -- once per communication schedule (overlap = auto, 0, 1, 2: "auto" times
     the other three and every rank must come out with the same one) -- and compares its planes of every field bit for
@@ -175,8 +175,8 @@ def slab_parity_check(F, fsdist, dist, rank, world, transport, ctl_device):
     want = {f: whole.get(f) for f in fields}
     ws = whole.stats(F.VX)                               # (sum, min, max) over the global grid
     whole.close()
-    bad, schedules = [], {}
-    for overlap in ("auto", "0", "1", "2") + (("3",) if transport == "ipc" else ()):
+    bad, ran = [], {}
+    for overlap in (schedules or ("auto", "0", "1", "2") + (("3",) if transport == "ipc" else ())):
         slab = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0, overlap=overlap)
         uid = fsdist.share_unique_id(dist, lambda: F.comm_unique_id(transport), rank, device=ctl_device)
         slab.comm_init(rank, world, uid)
@@ -195,12 +195,12 @@ def slab_parity_check(F, fsdist, dist, rank, world, transport, ctl_device):
             bad.append("ranks disagree on the schedule (overlap=%s)" % overlap)
         if slab._geti("stream_syncs") != 0:
             bad.append("a slab step synchronised the compute stream (overlap=%s)" % overlap)
-        schedules[overlap] = plan
+        ran[overlap] = plan
         slab.close()
     flag = fsdist.max_over_ranks(dist, 1.0 if bad else 0.0, device=ctl_device)
     if bad:
         sys.stderr.write("rank %d: z-slab run differs from the single-GPU run: %s\n" % (rank, bad))
-    return {"ok": flag == 0.0, "grid": [W, H, D], "steps": steps, "acc": acc, "schedule_run_under_overlap": schedules,
+    return {"ok": flag == 0.0, "grid": [W, H, D], "steps": steps, "acc": acc, "schedule_run_under_overlap": ran,
             "what": "every rank: its planes of dens/v/p/div of a %d-rank slab run vs the same run whole on its own GPU, bit-exact, "
                     "once per communication schedule (auto, 0, 1, 2)" % world}
 

@@ -115,6 +115,7 @@ struct fs_sim {
                                  // advection, so that the reach of the back-trace arrives on the host without stalling the device
     // slab-step bookkeeping readable through fs_get_int
     long n_stream_syncs = 0;     // host synchronisations of the compute stream issued by the slab step (reach fallback path)
+    long n_alloc_syncs = 0;      // ... by one-off allocations inside a step (the gathered sources at the first gather)
     long n_reach_waits = 0, n_reach_blocked = 0;   // waits for an asynchronously delivered reach; those that found it not yet there
     long n_reach_hidden = 0, n_reach_exposed = 0;  // gathers + advections queued while the device was still busy with the half density
                                                    // solve placed before them (hidden) / after it had run dry (exposed: a bubble)
@@ -206,6 +207,9 @@ struct Engine : EngineBase {
     fs_sim* S;
     fs::GridDesc g;       // local slab
     fs::SlabCtx sc;
+    T* pool_arena = nullptr;            // the one allocation behind arr[]
+    size_t pool_stride = 0;             // elements between consecutive arrays of the arena
+    T* gather_arena = nullptr;          // the one allocation behind gathered / gathered3 (z-slabs, allocated at the first gather)
     T* arr[NPOOL] = {nullptr};          // LEAD-shifted pointers
     int slot[FS_NFIELDS];               // field -> array id (aliases allowed inside a step)
     bool held[NPOOL] = {false};         // temporaries owned by a running solve
@@ -243,7 +247,7 @@ struct Engine : EngineBase {
     double vzmax_prev = -1.0;           // max |v_z| at the end of the previous step (= v_z_prev of this one), -1 = unknown
     double vzmax_end = -1.0;            // the same for the step that is running
     bool in_step = false;               // inside step(): the data flow between the solver's calls is known
-    static constexpr int SLOT_GATHER = NPOOL;   // FSIPC export slots: the pool arrays, then the gathered advection sources
+    static constexpr int SLOT_POOL = 0, SLOT_GATHER = 1, SLOT_MG = 2;   // FSIPC export slots: one per arena
     static constexpr int NRED = 3 * 1024 + 18;   // reduction scratch + up to six {sum, min, max} results (0, 1: stats / trace_reach; 2..4: post_vzmax)
 
     explicit Engine(fs_sim* s) : S(s) {}
@@ -278,12 +282,11 @@ struct Engine : EngineBase {
         sc.Dglobal = S->D;
         sc.lo_wall = (!cm.active() || cm.rank == 0) ? 1 : 0;
         sc.hi_wall = (!cm.active() || cm.rank == cm.nranks - 1) ? 1 : 0;
-        for (int i = 0; i < NPOOL; ++i) {
-            T* base = nullptr;
-            HIP_TRY(hipMalloc((void**)&base, g.n * sizeof(T)));
-            HIP_TRY(hipMemsetAsync(base, 0, g.n * sizeof(T), S->stream));   // simulation.cpp:38-43
-            arr[i] = base + g.lead;
-        }
+        // one allocation behind all field arrays (an arena: a slab rank exports it to its neighbours as ONE hipIpc handle)
+        pool_stride = (g.n + 63) / 64 * 64;              // keeps every array's first interior cell 16-byte aligned
+        HIP_TRY(hipMalloc((void**)&pool_arena, (size_t)NPOOL * pool_stride * sizeof(T)));
+        HIP_TRY(hipMemsetAsync(pool_arena, 0, (size_t)NPOOL * pool_stride * sizeof(T), S->stream));   // simulation.cpp:38-43
+        for (int i = 0; i < NPOOL; ++i) arr[i] = pool_arena + (size_t)i * pool_stride + g.lead;
         for (int f = 0; f < FS_NFIELDS; ++f) slot[f] = f;
         uint8_t* fb = nullptr;
         HIP_TRY(hipMalloc((void**)&fb, g.n));
@@ -303,9 +306,9 @@ struct Engine : EngineBase {
                 HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
             HIP_TRY(hipHostMalloc((void**)&reach_pinned, 9 * sizeof(double), hipHostMallocDefault));
             // FSIPC: the neighbours write straight into these arrays
-            for (int i = 0; i < NPOOL; ++i)
-                if (S->comm.register_buffer(i, arr[i] - g.lead, g.n * sizeof(T), false))
-                    return fail(FS_ECOMM, "exporting the field arrays: %s", S->comm.last_error());
+            HIP_TRY(hipStreamSynchronize(S->stream));
+            if (S->comm.register_buffer(SLOT_POOL, pool_arena, (size_t)NPOOL * pool_stride * sizeof(T), false))
+                return fail(FS_ECOMM, "exporting the field arrays: %s", S->comm.last_error());
             if (S->comm_cus != 0) {
                 // a second compute stream whose CU mask leaves CUs to the transport; mask bit i is CU i / 8 of XCD i % 8 (the
                 // driver deals the bits round-robin over the XCDs), so clearing the top bits takes the same number from every XCD
@@ -342,13 +345,10 @@ struct Engine : EngineBase {
 
     ~Engine() override
     {
-        for (int i = 0; i < NPOOL; ++i)
-            if (arr[i]) hipFree(arr[i] - g.lead);
+        if (pool_arena) hipFree(pool_arena);
         if (flags) hipFree(flags - g.lead);
         if (kill) hipFree(kill - (g.lead - fs::LEAD) / 4);
-        if (gathered) hipFree(gathered - fs::LEAD);   // global array with one ghost plane per side
-        for (T* gp : gathered3)
-            if (gp) hipFree(gp - fs::LEAD);
+        if (gather_arena) hipFree(gather_arena);      // the four gathered advection sources
         if (dense) hipFree(dense);
         if (red) hipFree(red);
         if (coltab) hipFree(coltab);
@@ -951,7 +951,6 @@ struct Engine : EngineBase {
     // kernel (its red-black instantiation is 1.6x slower and smooths no better here), the coarse levels live in
     // multigrid.hip.  Single GPU.
     int multigrid_levels() const override { return mg.levels(); }
-    static constexpr int SLOT_MG = NPOOL + 4;            // FSIPC export slot of the multigrid level arrays
     // the transport's part in the coarse levels of a slab run (multigrid.h): one-plane halo refreshes of distributed levels,
     // all-gathers at the seam to the levels every rank holds whole
     fs::MgHooks<T> mg_hooks()
@@ -1187,17 +1186,21 @@ struct Engine : EngineBase {
     // `which`: 0 = `gathered`, 1..3 = `gathered3` (the FSIPC export slot of the buffer)
     int gather_source(const T* src, T** buf, int reach, int which)
     {
-        const long n = g.sz * ((long)S->D + 2) + 8;
-        if (!*buf) {
-            T* base = nullptr;
-            HIP_TRY(hipMalloc((void**)&base, n * sizeof(T)));
-            HIP_TRY(hipMemsetAsync(base, 0, n * sizeof(T), S->stream));
-            *buf = base + fs::LEAD;
-            // every rank allocates it at the same point of the step: a collective export (FSIPC; the owners write into it)
-            if (S->comm.register_buffer(SLOT_GATHER + which, base, (size_t)n * sizeof(T), true))
-                return fail(FS_ECOMM, "exporting the gathered advection source: %s", S->comm.last_error());
+        const long n = (g.sz * ((long)S->D + 2) + 8 + 63) / 64 * 64;
+        if (!gather_arena) {
+            // all four at the first gather, as one arena: every rank allocates it at the same point of the step, so the
+            // export is collective (FSIPC: the owners of the planes write into it)
+            HIP_TRY(hipMalloc((void**)&gather_arena, (size_t)4 * n * sizeof(T)));
+            HIP_TRY(hipMemsetAsync(gather_arena, 0, (size_t)4 * n * sizeof(T), S->stream));
+            HIP_TRY(hipStreamSynchronize(S->stream));
+            ++S->n_alloc_syncs;
+            if (S->comm.register_buffer(SLOT_GATHER, gather_arena, (size_t)4 * n * sizeof(T), true))
+                return fail(FS_ECOMM, "exporting the gathered advection sources: %s", S->comm.last_error());
+            gathered = gather_arena + fs::LEAD;
+            for (int k = 0; k < 3; ++k) gathered3[k] = gather_arena + (size_t)(1 + k) * n + fs::LEAD;
         }
-        if (S->debug_poison) HIP_TRY(hipMemsetAsync(*buf - fs::LEAD, 0xFF, n * sizeof(T), S->stream));
+        (void)which;
+        if (S->debug_poison) HIP_TRY(hipMemsetAsync(*buf - fs::LEAD, 0xFF, (g.sz * ((long)S->D + 2) + 8) * sizeof(T), S->stream));
         T* dst = *buf;
         return comm_op([&](hipStream_t st) {
             return (reach >= S->D) ? S->comm.all_gather_planes(st, src, dst, g, S->D, sizeof(T))
@@ -1879,7 +1882,12 @@ int fs_set_option(fs_sim* s, const char* key, const char* value)
         if (v == "cell") s->tune.advect_cell = 1;
         else if (v == "celltab") s->tune.advect_cell = 2;
         else if (v == "row") s->tune.advect_cell = 0;
-        else return fail(FS_EINVAL, "advect_kernels: cell | celltab | row");
+        else if (v == "tile") s->tune.advect_cell = 3;
+        else return fail(FS_EINVAL, "advect_kernels: cell | celltab | tile | row");
+    } else if (k == "advect_window") {
+        const int n = atoi(value);
+        if (n < 1 || n > 128) return fail(FS_EINVAL, "advect_window: 1 .. 128");
+        s->tune.advect_window = n;
     } else if (k == "wall_free") {
         if (v == "0") s->tune.wall_free = 0;
         else if (v == "auto") s->tune.wall_free = 1;

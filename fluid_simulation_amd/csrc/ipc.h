@@ -105,7 +105,7 @@ __global__ void ipc_reduce_kernel(IpcReduceArgs a)
 
 struct IpcTransport {
     struct Header {
-        std::atomic<int> count, generation, ready;
+        std::atomic<int> count, generation, ready, veto;
         unsigned error;                                  // written by the device (first timed-out operation), 0 = none
         hipIpcMemHandle_t handle[IPC_MAXR][IPC_MAXBUF];
         size_t bytes[IPC_MAXR][IPC_MAXBUF];
@@ -129,6 +129,7 @@ struct IpcTransport {
     Buf bufs[IPC_MAXBUF];
     unsigned seq = 0;          // operation counter: every rank issues the same operations in the same order
     unsigned nred = 0;         // reductions issued (selects the row of red / vals)
+    unsigned nregistered = 0;  // allocations exported so far (every rank registers the same ones in the same order)
     long long timeout_ticks = 0;
     bool registered = false;
     long ops = 0, copies = 0;  // diagnostics
@@ -202,8 +203,16 @@ struct IpcTransport {
     {
         if (slot < 0 || slot >= IPC_MAXBUF) { *err = "FSIPC: buffer slot out of range"; return -1; }
         if (open(err)) return -1;
-        hipError_t e = hipIpcGetMemHandle(&hdr->handle[rank][slot], base);
-        if (e != hipSuccess) { *err = std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e); hdr->bytes[rank][slot] = 0; }
+        // The owner marks the first and the last 16 bytes of the allocation with {magic, rank, slot, registration count}
+        // before it exports it; whoever maps it reads both marks back through the mapping.  A mapping that points somewhere
+        // else (a stale or aliased handle) is refused here instead of corrupting a run later.  The marks are cleared again:
+        // exports happen on freshly zeroed allocations.
+        ++nregistered;
+        const unsigned mark[4] = { 0xF51DC0DEu, (unsigned)rank, (unsigned)slot, nregistered };
+        hipError_t e = (bytes >= 32) ? hipMemcpy(base, mark, sizeof mark, hipMemcpyHostToDevice) : hipErrorInvalidValue;
+        if (e == hipSuccess) e = hipMemcpy(static_cast<char*>(base) + bytes - sizeof mark, mark, sizeof mark, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&hdr->handle[rank][slot], base);
+        if (e != hipSuccess) { *err = std::string("exporting an allocation (hipIpcGetMemHandle): ") + hipGetErrorString(e); hdr->bytes[rank][slot] = 0; }
         else hdr->bytes[rank][slot] = bytes;
         barrier();
         int rc = (e == hipSuccess) ? 0 : -1;
@@ -216,8 +225,27 @@ struct IpcTransport {
             e = hipIpcOpenMemHandle(&p, hdr->handle[r][slot], hipIpcMemLazyEnablePeerAccess);
             if (e != hipSuccess) { *err = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e); rc = -1; break; }
             bufs[slot].peer[r] = static_cast<char*>(p);
+            unsigned got[8] = {0};
+            e = hipMemcpy(got, p, 16, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(got + 4, static_cast<char*>(p) + bytes - 16, 16, hipMemcpyDeviceToHost);
+            const unsigned want[4] = { 0xF51DC0DEu, (unsigned)r, (unsigned)slot, nregistered };
+            if (e != hipSuccess || memcmp(got, want, 16) != 0 || memcmp(got + 4, want, 16) != 0) {
+                *err = "FSIPC: the mapping of rank " + std::to_string(r) + "'s allocation " + std::to_string(slot) +
+                       " does not show that allocation (stale or aliased hipIpc handle)";
+                rc = -1;
+                break;
+            }
         }
+        barrier();                                       // everybody has looked: the marks go
+        if (bytes >= 32) {
+            (void)hipMemset(base, 0, 16);
+            (void)hipMemset(static_cast<char*>(base) + bytes - 16, 0, 16);
+            (void)hipDeviceSynchronize();
+        }
+        // all ranks or none: a rank whose mapping failed must not leave the others exchanging with it
+        if (rc) hdr->veto.fetch_add(1, std::memory_order_acq_rel);
         barrier();
+        if (!rc && hdr->veto.load(std::memory_order_acquire) != 0) { *err = "FSIPC: another rank could not map an allocation"; rc = -1; }
         return rc;
     }
 

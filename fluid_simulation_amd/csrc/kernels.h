@@ -52,8 +52,11 @@ struct SweepTune {
     int pair_zc = 0;          // planes per z chunk of the pair kernel; 0 = automatic
     int project_cell = 0;     // 1 = per-cell divergence/gradient kernels instead of the z-marching ones
     int pair_shape = 0;       // >0 forces a pair-kernel workgroup shape (1 = 8, 2 = 10, 3 = 16 waves); 0 = timed choice
-    int advect_cell = 1;      // 1 (default) = per-cell advection kernels; 2 = the same with clamp tables; 0 = the row kernels (four
+    int advect_cell = 1;      // 1 (default) = per-cell advection kernels; 2 = the same with clamp tables; 3 = the tile kernels (clamp
+                              // tables staged in LDS, for rough flows; single GPU, else as 2); 0 = the row kernels (four
                               // cells per lane + clamp tables); bit-identical, within 5 % of each other (profiles/r03e_*, r02g_*)
+    int advect_window = 24;   // advect_cell == 3 (the tile kernels): rows / planes around a tile whose inlet-table values are staged in
+                              // LDS; a trace that ends further away takes the per-cell path (capped by what 64 KB of LDS hold)
     int wall_free = 1;        // three-sweep kernel, whole-domain aligned grids: workgroups that touch no y / z wall run a wall-free
                               // second body -- 0 never, 1 (default) when a launch has more than 256 workgroups, 2 always
     int two_kind = 0;         // which two-sweep kernel: 0 = timed choice, 1 = jacobi_pair_kernel only, 2 = jacobi_fused_kernel<NL=2> only

@@ -1468,6 +1468,110 @@ __global__ __launch_bounds__(256) void advect_velocity_row_kernel(GridDesc g, Sl
     store_row_bounds<T>(g, sc, vz, c, x0, y, z, nz, near4, 3);
 }
 
+// ---- tile form (option advect_kernels=tile; round 3) ---------------------------------------------------------------
+// Where the flow is rough (the properly projected flow of solver=mg: |u_y|, |u_z| of order one, i.e. traces that leave
+// their cell by tens of rows and planes) the 64 traces of a wave end in up to 64 different cache lines per load and the
+// per-cell kernels spend their time in the L2 -> L1 path.  The x coordinate still clamps to the
+// inlet for almost every trace, so what is gathered is the x-interpolated inlet column table (advect_columns_kernel):
+// a workgroup owns TY x TZ (y, z) rows of cells over the whole row length, stages the window of that table that
+// traces of at most R rows / planes can reach in LDS -- coalesced, once per 32 K cells -- and gathers from there; a
+// trace that leaves the window, or does not clamp, takes the per-cell path (global table or array).  Same table values,
+// same expressions: bit-identical with the other forms.
+template <class T, int NF>
+__global__ __launch_bounds__(1024) void advect_tile_kernel(GridDesc g, SlabCtx sc, int b, T* __restrict__ f0, T* __restrict__ f1,
+                                                            T* __restrict__ f2, const T* __restrict__ p0, const T* __restrict__ p1,
+                                                            const T* __restrict__ p2, const T* vx, const T* vy, const T* vz,
+                                                            const uint8_t* __restrict__ flags, T kx, T ky, T kz,
+                                                            const T* __restrict__ tab, int R)
+{
+    constexpr int TY = 8, TZ = 8;
+    extern __shared__ unsigned char win_raw[];
+    T* win = reinterpret_cast<T*>(win_raw);
+    const int ty0 = 1 + blockIdx.x * TY, tz0 = 1 + blockIdx.y * TZ;
+    // window of table rows (y) and planes (z) this tile's traces can reach, clipped to the table
+    const int wy0 = max(0, ty0 - R), wy1 = min(g.H + 1, ty0 + TY + R), wz0 = max(0, tz0 - R), wz1 = min(g.D + 1, tz0 + TZ + R);
+    const int WY = wy1 - wy0 + 1, WZ = wz1 - wz0 + 1;
+    const long tplane = (long)(g.H + 2) * (g.D + 2);
+    for (int k = 0; k < NF; ++k) {
+        const T* t = tab + 2 * k * tplane;                   // the inlet side of source k
+        for (int i = threadIdx.x; i < WY * WZ; i += 1024) {
+            const int yy = i % WY, zz = i / WY;
+            win[(long)k * WY * WZ + i] = t[(wy0 + yy) + (long)(wz0 + zz) * (g.H + 2)];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const T one = (T)1, half = (T)0.5;
+    // one trace of source k (arguments as back_trace_tab)
+    auto trace = [&](int k, const T* src, int x, int y, int z, T ux, T uy, T uz) -> T {
+        const T px = clamp_ref<T>((T)x - kx * ux, half, (T)g.W + half);          // :384-390
+        const T py = clamp_ref<T>((T)y - ky * uy, half, (T)g.H + half);
+        const T pz = clamp_ref<T>((T)z - kz * uz, half, (T)g.D + half);
+        const int y0 = (int)floor(py), z0 = (int)floor(pz);
+        if (px == half && y0 >= wy0 && y0 + 1 <= wy1 && z0 >= wz0 && z0 + 1 <= wz1) {
+            const T ty = py - (T)y0, tz = pz - (T)z0;
+            const T* w = win + (long)k * WY * WZ + (y0 - wy0) + (long)(z0 - wz0) * WY;
+            const T a00 = w[0], a10 = w[1], a01 = w[WY], a11 = w[WY + 1];
+            const T b0 = a00 * (one - ty) + a10 * ty;                         // :417-418
+            const T b1 = a01 * (one - ty) + a11 * ty;
+            return b0 * (one - tz) + b1 * tz;                                 // :420
+        }
+        return back_trace_tab<T>(g, sc, src, 0, tab + 2 * k * tplane, x, y, z, ux, uy, uz, kx, ky, kz);
+    };
+    // 16 waves share the TY x TZ rows of the tile; a wave walks its rows 64 cells at a time
+    for (int row = wave; row < TY * TZ; row += 16) {
+        const int y = ty0 + row % TY, z = tz0 + row / TY;
+        if (y > g.H || z > g.D) continue;                    // wave-uniform
+        for (int x = 1 + lane; x <= g.W; x += 64) {
+            const long c = cell(g, x, y, z);
+            const unsigned f = flags[c];
+            const bool near = (f & F_NEAR) != 0;
+            if constexpr (NF == 1) {
+                T u = (T)0;
+                if (!(f & F_SOLID)) {
+                    T ux, uy, uz;
+                    if (b == 0) {                            // uniform
+                        ux = vx[c]; uy = vy[c]; uz = vz[c];
+                    } else {
+                        const T own = p0[c];
+                        ux = (b == 1) ? own : vx[c];         // :380-382
+                        uy = (b == 2) ? own : vy[c];
+                        uz = (b == 3) ? own : vz[c];
+                    }
+                    u = trace(0, p0, x, y, z, ux, uy, uz);
+                }
+                f0[c] = ((b != 0) && near) ? (T)0 : u;
+                write_face_ghosts(g, sc, f0, c, x, y, z, u, b);
+            } else {
+                T nx = (T)0, ny = (T)0, nz = (T)0;           // un-zeroed results (0 inside solids, :375-377)
+                if (!(f & F_SOLID)) {
+                    const T oy = f1[c], oz = f2[c];          // f0, f1, f2 = v_x, v_y, v_z: read at the own cell, then overwritten
+                    nx = trace(0, p0, x, y, z, p0[c], oy, oz);
+                    const T sx = near ? (T)0 : nx;           // what setBounds leaves in v_x
+                    ny = trace(1, p1, x, y, z, sx, p1[c], oz);
+                    const T sy = near ? (T)0 : ny;
+                    nz = trace(2, p2, x, y, z, sx, sy, p2[c]);
+                }
+                f0[c] = near ? (T)0 : nx;
+                f1[c] = near ? (T)0 : ny;
+                f2[c] = near ? (T)0 : nz;
+                write_face_ghosts(g, sc, f0, c, x, y, z, nx, 1);
+                write_face_ghosts(g, sc, f1, c, x, y, z, ny, 2);
+                write_face_ghosts(g, sc, f2, c, x, y, z, nz, 3);
+            }
+        }
+    }
+}
+
+// window radius that fits 64 KB of LDS for NF staged tables (the tile is 8 x 8 rows)
+template <class T>
+static int tile_window(int want, int nf)
+{
+    int r = want < 1 ? 1 : want;
+    while (r > 1 && (long)nf * (8 + 2 * r + 1) * (8 + 2 * r + 1) * (long)sizeof(T) > 64 * 1024) --r;
+    return r;
+}
+
 static inline dim3 row_grid(const GridDesc& g) { return dim3((g.W + 255) / 256, (g.H + 3) / 4, g.D); }
 
 // the clamp tables only describe a source array that is this GPU's whole domain (a slab traces into the gathered array)
@@ -1488,6 +1592,13 @@ void launch_advect_velocity(hipStream_t st, const SweepTune& tune, const GridDes
                             T ky, T kz, long zshift)
 {
     const T* tab = (tune.advect_cell == 1) ? nullptr : build_columns<T>(st, g, sc, px, py, pz, 3, coltab, zshift);
+    if (tune.advect_cell == 3 && tab) {
+        const int R = tile_window<T>(tune.advect_window, 3);
+        const size_t lds = (size_t)3 * (8 + 2 * R + 1) * (8 + 2 * R + 1) * sizeof(T);
+        hipLaunchKernelGGL((advect_tile_kernel<T, 3>), dim3((g.H + 7) / 8, (g.D + 7) / 8), dim3(1024), lds, st, g, sc, 0, vx, vy, vz, px,
+                           py, pz, vx, vy, vz, flags, kx, ky, kz, tab, R);
+        return;
+    }
     if (tune.advect_cell) {
         if (tab)
             hipLaunchKernelGGL((advect_velocity_kernel<T, true>), cell_grid(g), cell_block(), 0, st, g, sc, vx, vy, vz, px, py,
@@ -1513,6 +1624,13 @@ void launch_advect(hipStream_t st, const SweepTune& tune, const GridDesc& g, con
                    long prev_zshift)
 {
     const T* tab = (tune.advect_cell == 1) ? nullptr : build_columns<T>(st, g, sc, prev, prev, prev, 1, coltab, prev_zshift);
+    if (tune.advect_cell == 3 && tab) {
+        const int R = tile_window<T>(tune.advect_window, 1);
+        const size_t lds = (size_t)(8 + 2 * R + 1) * (8 + 2 * R + 1) * sizeof(T);
+        hipLaunchKernelGGL((advect_tile_kernel<T, 1>), dim3((g.H + 7) / 8, (g.D + 7) / 8), dim3(1024), lds, st, g, sc, b, field, field,
+                           field, prev, prev, prev, vx, vy, vz, flags, kx, ky, kz, tab, R);
+        return;
+    }
     if (tune.advect_cell) {
         if (tab)
             hipLaunchKernelGGL((advect_kernel<T, true>), cell_grid(g), cell_block(), 0, st, g, sc, b, field, prev, vx, vy, vz,

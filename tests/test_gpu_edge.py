@@ -157,6 +157,9 @@ def test_advection_row_kernels_match_cell_kernels_and_oracle(F, oracle_mod, spee
     m = ball_mask(W, H, D, W / 3.0, H / 2.0, D / 2.0, min(W, H, D) / 4.0)
     m[1, 1, 1] = m[D, H, W] = True
     sims = [F.Simulation(W, H, D, 1, speed=speed, acc=4, quiet=1, advect_kernels=k, **kw) for k in ("row", "cell", "celltab")]
+    # the tile kernels (inlet table windows staged in LDS): a window of 1 row / plane (most traces leave it and take the
+    # per-cell path) and the default one
+    sims += [F.Simulation(W, H, D, 1, speed=speed, acc=4, quiet=1, advect_kernels="tile", advect_window=w, **kw) for w in (1, 24)]
     ora = O.Oracle(W, H, D, solver=O.JACOBI, fp64=fp64, threads=4, speed=speed, acc=4)
     for x in sims + [ora]:
         x.set_mask(m)
@@ -166,6 +169,8 @@ def test_advection_row_kernels_match_cell_kernels_and_oracle(F, oracle_mod, spee
     for f in range(11):
         assert bits_equal(sims[0].get(f), sims[1].get(f)), "row vs cell: %s" % F.FIELD_NAMES[f]
         assert bits_equal(sims[2].get(f), sims[1].get(f)), "cell with clamp tables vs cell: %s" % F.FIELD_NAMES[f]
+        assert bits_equal(sims[3].get(f), sims[1].get(f)), "tile kernels, window 1, vs cell: %s" % F.FIELD_NAMES[f]
+        assert bits_equal(sims[4].get(f), sims[1].get(f)), "tile kernels vs cell: %s" % F.FIELD_NAMES[f]
     same_state(F, O, sims[0], ora, "advection row kernels, speed %d" % speed)
     for s_ in sims:
         s_.set_option("fuse_advect", "0")                # the three velocity advections as separate launches
@@ -174,6 +179,8 @@ def test_advection_row_kernels_match_cell_kernels_and_oracle(F, oracle_mod, spee
     same_state(F, O, sims[0], ora, "unfused row kernels, speed %d" % speed)
     same_state(F, O, sims[1], ora, "unfused cell kernels, speed %d" % speed)
     same_state(F, O, sims[2], ora, "unfused cell kernels with clamp tables, speed %d" % speed)
+    same_state(F, O, sims[3], ora, "unfused tile kernels (window 1), speed %d" % speed)
+    same_state(F, O, sims[4], ora, "unfused tile kernels, speed %d" % speed)
 
 
 def test_three_sweeps_per_pass_kernel_full_rows(F):

@@ -20,7 +20,7 @@ acc = int(sys.argv[3]) if len(sys.argv) > 3 else cfg["acc"]
 solver = sys.argv[4] if len(sys.argv) > 4 else "jacobi"
 out = {"workload": name, "precision": prec, "acc": acc, "solver": solver}
 for rep in range(2):
-    for kind in ("row", "celltab", "cell"):
+    for kind in ("row", "celltab", "cell", "tile"):
         sim = F.Simulation(cfg["W"], cfg["H"], cfg["D"], 1, acc=acc, precision=prec, quiet=1, dump_every=0, profile=1,
                            advect_kernels=kind, solver=solver)
         with tempfile.TemporaryDirectory() as tmp:

@@ -3,7 +3,7 @@
 // `iters` neighbour exchanges (the halo pattern: my first/last block -> the neighbours' ghost blocks) plus
 // reductions, all stream-ordered with no host synchronisation inside the loop, and checks every received block.
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/ipc_probe.cpp -o build/ipc_probe -lrt -lpthread
-//   ./build/ipc_probe [ranks=3] [iters=200] [MiB per block=2]
+//   ./tools/ipc_probe [ranks=3] [iters=200] [MiB per block=2] [cycles=1]
 #include "../fluid_simulation_amd/csrc/ipc.h"
 
 #include <sys/wait.h>
@@ -96,14 +96,21 @@ int main(int argc, char** argv)
 {
     const int nranks = argc > 1 ? atoi(argv[1]) : 3;
     const int iters = argc > 2 ? atoi(argv[2]) : 200;
-    const size_t block_words = (size_t)(argc > 3 ? atof(argv[3]) : 2.0) * 262144;
+    const size_t block_words = (size_t)((argc > 3 ? atof(argv[3]) : 2.0) * 262144);
+    const int cycles = argc > 4 ? atoi(argv[4]) : 1;
     char name[64];
     snprintf(name, sizeof name, "/fs_ipc_probe_%d", (int)getpid());
     std::vector<pid_t> kids;
     for (int r = 0; r < nranks; ++r) {
         pid_t p = fork();                                // before any HIP call: every rank initialises the GPU itself
         if (p == 0) {
-            const int rc = run_rank(r, nranks, name, iters, block_words);
+            // `cycles` transports one after the other in the same process (allocation, export, mapping and teardown repeat)
+            int rc = 0;
+            for (int c = 0; c < cycles && !rc; ++c) {
+                char nm[96];
+                snprintf(nm, sizeof nm, "%s_%d", name, c);
+                rc = run_rank(r, nranks, nm, iters, block_words);
+            }
             fflush(stdout);
             _exit(rc);
         }

@@ -22,7 +22,7 @@ for i in range(n):
     acc, steps = int(rng.integers(0, 10)), int(rng.integers(1, 3))
     fp64 = bool(rng.random() < 0.35)
     opts = {"sweep_fuse": str(rng.choice([2, 3, 4, 4])), "two_sweep_kernel": str(rng.choice(["auto", "pair", "fused"])),
-            "advect_kernels": str(rng.choice(["cell", "row", "celltab"])), "fuse_advect": str(rng.choice([0, 1])), "wall_free": str(rng.choice(["auto", "0", "1"]))}
+            "advect_kernels": str(rng.choice(["cell", "row", "celltab", "tile"])), "fuse_advect": str(rng.choice([0, 1])), "wall_free": str(rng.choice(["auto", "0", "1"]))}
     speed = int(rng.choice([30, 30, 3, -10]))
     sim = F.Simulation(W, H, D, steps, speed=speed, acc=acc, quiet=1, precision="fp64" if fp64 else "fp32", **opts)
     ora = O.Oracle(W, H, D, solver=O.JACOBI, fp64=fp64, threads=8, speed=speed, acc=acc)
