@@ -202,7 +202,7 @@ def slab_parity_check(F, fsdist, dist, rank, world, transport, ctl_device, sched
         sys.stderr.write("rank %d: z-slab run differs from the single-GPU run: %s\n" % (rank, bad))
     return {"ok": flag == 0.0, "grid": [W, H, D], "steps": steps, "acc": acc, "schedule_run_under_overlap": ran,
             "what": "every rank: its planes of dens/v/p/div of a %d-rank slab run vs the same run whole on its own GPU, bit-exact, "
-                    "once per communication schedule (auto, 0, 1, 2)" % world}
+                    "once per communication schedule (%s)" % (world, ", ".join(ran))}
 
 
 def main():
@@ -267,11 +267,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def trace(msg):
+        if os.environ.get("FS_BENCH_TRACE"):
+            sys.stderr.write("bench rank %d: %s\n" % (rank, msg))
+            sys.stderr.flush()
+
     slab_parity = None
     if world > 1:
         from fluid_simulation_amd import dist as fsdist
-        slab_parity = slab_parity_check(F, fsdist, dist, rank, world, args.transport, ctl_device)
+        if os.environ.get("FS_BENCH_SKIP_PARITY"):       # development only: the line then carries slab_parity = null
+            trace("parity check SKIPPED (FS_BENCH_SKIP_PARITY)")
+        else:
+            slab_parity = slab_parity_check(F, fsdist, dist, rank, world, args.transport, ctl_device)
 
+    trace("parity check done: %s" % (slab_parity,))
     sim = F.Simulation(W, H, D, args.steps, acc=acc, precision=args.precision, quiet=1, dump_every=0, profile=1,
                        overlap=args.overlap, comm_cus=args.comm_cus)
     if args.launch_plans:
@@ -282,9 +291,12 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         added = add_obstacles(F, sim, cfg, tmp)
 
+    trace("obstacles in: %s" % (added,))
     for _ in range(args.warmup):
         sim.run_one()
+        trace("warm-up step queued")
     sim.sync()
+    trace("warm-up done")
     sim.reset_timing()
     barrier()
     t0 = time.perf_counter()

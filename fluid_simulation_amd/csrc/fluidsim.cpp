@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -207,9 +208,12 @@ struct Engine : EngineBase {
     fs_sim* S;
     fs::GridDesc g;       // local slab
     fs::SlabCtx sc;
-    T* pool_arena = nullptr;            // the one allocation behind arr[]
-    size_t pool_stride = 0;             // elements between consecutive arrays of the arena
-    T* gather_arena = nullptr;          // the one allocation behind gathered / gathered3 (z-slabs, allocated at the first gather)
+    static constexpr size_t ARENA_CHUNK_BYTES = (size_t)1 << 30;
+    std::vector<T*> pool_chunks;        // the allocations behind arr[]: pool_per arrays each, pool_stride elements apart
+    std::vector<size_t> pool_chunk_bytes;
+    size_t pool_stride = 0;
+    int pool_per = 1;
+    std::vector<T*> gather_chunks;      // the same behind gathered / gathered3 (z-slabs, allocated at the first gather)
     T* arr[NPOOL] = {nullptr};          // LEAD-shifted pointers
     int slot[FS_NFIELDS];               // field -> array id (aliases allowed inside a step)
     bool held[NPOOL] = {false};         // temporaries owned by a running solve
@@ -247,7 +251,7 @@ struct Engine : EngineBase {
     double vzmax_prev = -1.0;           // max |v_z| at the end of the previous step (= v_z_prev of this one), -1 = unknown
     double vzmax_end = -1.0;            // the same for the step that is running
     bool in_step = false;               // inside step(): the data flow between the solver's calls is known
-    static constexpr int SLOT_POOL = 0, SLOT_GATHER = 1, SLOT_MG = 2;   // FSIPC export slots: one per arena
+    static constexpr int SLOT_POOL = 0, SLOT_GATHER = NPOOL, SLOT_MG = NPOOL + 4;   // FSIPC export slots: one per arena chunk
     static constexpr int NRED = 3 * 1024 + 18;   // reduction scratch + up to six {sum, min, max} results (0, 1: stats / trace_reach; 2..4: post_vzmax)
 
     explicit Engine(fs_sim* s) : S(s) {}
@@ -282,11 +286,22 @@ struct Engine : EngineBase {
         sc.Dglobal = S->D;
         sc.lo_wall = (!cm.active() || cm.rank == 0) ? 1 : 0;
         sc.hi_wall = (!cm.active() || cm.rank == cm.nranks - 1) ? 1 : 0;
-        // one allocation behind all field arrays (an arena: a slab rank exports it to its neighbours as ONE hipIpc handle)
+        // The field arrays live in a few large allocations ("arena chunks"), not one hipMalloc each: a slab rank exports
+        // every chunk to its neighbours as one hipIpc handle.  Many small exports alias after a few handles of one process,
+        // and an export beyond 2 GiB never returns on the HIP runtime PyTorch bundles (both seen in round 3's bench
+        // rehearsals), so a chunk holds as many arrays as fit 1 GiB.
         pool_stride = (g.n + 63) / 64 * 64;              // keeps every array's first interior cell 16-byte aligned
-        HIP_TRY(hipMalloc((void**)&pool_arena, (size_t)NPOOL * pool_stride * sizeof(T)));
-        HIP_TRY(hipMemsetAsync(pool_arena, 0, (size_t)NPOOL * pool_stride * sizeof(T), S->stream));   // simulation.cpp:38-43
-        for (int i = 0; i < NPOOL; ++i) arr[i] = pool_arena + (size_t)i * pool_stride + g.lead;
+        pool_per = (int)std::max<size_t>(1, ARENA_CHUNK_BYTES / (pool_stride * sizeof(T)));
+        if (pool_per > NPOOL) pool_per = NPOOL;
+        for (int i = 0; i < NPOOL; i += pool_per) {
+            const size_t cnt = (size_t)std::min(pool_per, NPOOL - i) * pool_stride;
+            T* chunk = nullptr;
+            HIP_TRY(hipMalloc((void**)&chunk, cnt * sizeof(T)));
+            pool_chunks.push_back(chunk);
+            pool_chunk_bytes.push_back(cnt * sizeof(T));
+            HIP_TRY(hipMemsetAsync(chunk, 0, cnt * sizeof(T), S->stream));   // simulation.cpp:38-43
+        }
+        for (int i = 0; i < NPOOL; ++i) arr[i] = pool_chunks[(size_t)(i / pool_per)] + (size_t)(i % pool_per) * pool_stride + g.lead;
         for (int f = 0; f < FS_NFIELDS; ++f) slot[f] = f;
         uint8_t* fb = nullptr;
         HIP_TRY(hipMalloc((void**)&fb, g.n));
@@ -307,8 +322,9 @@ struct Engine : EngineBase {
             HIP_TRY(hipHostMalloc((void**)&reach_pinned, 9 * sizeof(double), hipHostMallocDefault));
             // FSIPC: the neighbours write straight into these arrays
             HIP_TRY(hipStreamSynchronize(S->stream));
-            if (S->comm.register_buffer(SLOT_POOL, pool_arena, (size_t)NPOOL * pool_stride * sizeof(T), false))
-                return fail(FS_ECOMM, "exporting the field arrays: %s", S->comm.last_error());
+            for (size_t k = 0; k < pool_chunks.size(); ++k)
+                if (S->comm.register_buffer(SLOT_POOL + (int)k, pool_chunks[k], pool_chunk_bytes[k], false))
+                    return fail(FS_ECOMM, "exporting the field arrays: %s", S->comm.last_error());
             if (S->comm_cus != 0) {
                 // a second compute stream whose CU mask leaves CUs to the transport; mask bit i is CU i / 8 of XCD i % 8 (the
                 // driver deals the bits round-robin over the XCDs), so clearing the top bits takes the same number from every XCD
@@ -345,10 +361,10 @@ struct Engine : EngineBase {
 
     ~Engine() override
     {
-        if (pool_arena) hipFree(pool_arena);
+        for (T* c : pool_chunks) hipFree(c);
         if (flags) hipFree(flags - g.lead);
         if (kill) hipFree(kill - (g.lead - fs::LEAD) / 4);
-        if (gather_arena) hipFree(gather_arena);      // the four gathered advection sources
+        for (T* c : gather_chunks) hipFree(c);        // the four gathered advection sources
         if (dense) hipFree(dense);
         if (red) hipFree(red);
         if (coltab) hipFree(coltab);
@@ -1187,17 +1203,27 @@ struct Engine : EngineBase {
     int gather_source(const T* src, T** buf, int reach, int which)
     {
         const long n = (g.sz * ((long)S->D + 2) + 8 + 63) / 64 * 64;
-        if (!gather_arena) {
-            // all four at the first gather, as one arena: every rank allocates it at the same point of the step, so the
-            // export is collective (FSIPC: the owners of the planes write into it)
-            HIP_TRY(hipMalloc((void**)&gather_arena, (size_t)4 * n * sizeof(T)));
-            HIP_TRY(hipMemsetAsync(gather_arena, 0, (size_t)4 * n * sizeof(T), S->stream));
+        if (gather_chunks.empty()) {
+            // all four at the first gather, in arena chunks like the field arrays: every rank allocates them at the same
+            // point of the step, so the export is collective (FSIPC: the owners of the planes write into them)
+            const int per = (int)std::min<size_t>(4, std::max<size_t>(1, ARENA_CHUNK_BYTES / ((size_t)n * sizeof(T))));
+            T* at[4];
+            for (int i = 0; i < 4; i += per) {
+                const size_t cnt = (size_t)std::min(per, 4 - i) * (size_t)n;
+                T* chunk = nullptr;
+                HIP_TRY(hipMalloc((void**)&chunk, cnt * sizeof(T)));
+                gather_chunks.push_back(chunk);
+                HIP_TRY(hipMemsetAsync(chunk, 0, cnt * sizeof(T), S->stream));
+                for (int j = 0; j < per && i + j < 4; ++j) at[i + j] = chunk + (size_t)j * (size_t)n;
+            }
             HIP_TRY(hipStreamSynchronize(S->stream));
             ++S->n_alloc_syncs;
-            if (S->comm.register_buffer(SLOT_GATHER, gather_arena, (size_t)4 * n * sizeof(T), true))
-                return fail(FS_ECOMM, "exporting the gathered advection sources: %s", S->comm.last_error());
-            gathered = gather_arena + fs::LEAD;
-            for (int k = 0; k < 3; ++k) gathered3[k] = gather_arena + (size_t)(1 + k) * n + fs::LEAD;
+            for (size_t k = 0; k < gather_chunks.size(); ++k)
+                if (S->comm.register_buffer(SLOT_GATHER + (int)k, gather_chunks[k],
+                                            (size_t)std::min(per, 4 - (int)k * per) * (size_t)n * sizeof(T), true))
+                    return fail(FS_ECOMM, "exporting the gathered advection sources: %s", S->comm.last_error());
+            gathered = at[0] + fs::LEAD;
+            for (int k = 0; k < 3; ++k) gathered3[k] = at[1 + k] + fs::LEAD;
         }
         (void)which;
         if (S->debug_poison) HIP_TRY(hipMemsetAsync(*buf - fs::LEAD, 0xFF, (g.sz * ((long)S->D + 2) + 8) * sizeof(T), S->stream));

@@ -23,6 +23,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -207,7 +208,14 @@ struct IpcTransport {
         // before it exports it; whoever maps it reads both marks back through the mapping.  A mapping that points somewhere
         // else (a stale or aliased handle) is refused here instead of corrupting a run later.  The marks are cleared again:
         // exports happen on freshly zeroed allocations.
+        if (bytes > ((size_t)2 << 30) - 4096) {
+            // an export beyond 2 GiB never returns on the HIP runtime PyTorch bundles (round 3); nobody has entered a barrier yet
+            *err = "FSIPC: an allocation of " + std::to_string(bytes >> 20) + " MiB cannot be exported (2 GiB per hipIpc handle); use more ranks, or RCCL";
+            return -1;
+        }
         ++nregistered;
+        const bool trace = getenv("FS_IPC_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "fsipc rank %d: exporting allocation %d (%zu MiB)\n", rank, slot, bytes >> 20);
         const unsigned mark[4] = { 0xF51DC0DEu, (unsigned)rank, (unsigned)slot, nregistered };
         hipError_t e = (bytes >= 32) ? hipMemcpy(base, mark, sizeof mark, hipMemcpyHostToDevice) : hipErrorInvalidValue;
         if (e == hipSuccess) e = hipMemcpy(static_cast<char*>(base) + bytes - sizeof mark, mark, sizeof mark, hipMemcpyHostToDevice);
@@ -236,6 +244,7 @@ struct IpcTransport {
                 break;
             }
         }
+        if (trace) fprintf(stderr, "fsipc rank %d: allocation %d mapped (rc %d)\n", rank, slot, rc);
         barrier();                                       // everybody has looked: the marks go
         if (bytes >= 32) {
             (void)hipMemset(base, 0, 16);

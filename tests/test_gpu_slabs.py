@@ -274,3 +274,23 @@ def test_slabs_multigrid_matches_single_gpu(tmp_path, W, H, D, nranks, precision
             assert np.array_equal(got[lo:hi].view(u), want[lo:hi].view(u)), (r, k)
         assert int(z["sched"][0]) == 0
     assert np.abs(ref["pressure"]).max() > 0
+
+
+def test_bench_slab_parity_rehearsal_repeated_handles(tmp_path):
+    """bench.py's own N > 1 parity check (every communication schedule in turn, each on a fresh slab handle and a fresh
+    FSIPC transport), four rank processes sharing the GPU, twice over -- ten slab handles per process, launched exactly
+    like the bench (torch.distributed.run, torch imported first).  Round 3 found this way that many small exported
+    allocations alias after a few handles of one process (wrong planes, then hipIpcGetMemHandle: invalid argument); the
+    library now exports one arena per handle and verifies every mapping."""
+    ok, why = ipc_usable()
+    if not ok:
+        pytest.skip("FSIPC transport not usable on this box: " + why)
+    port = 29700 + os.getpid() % 200
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "parity_rehearsal.py"), "ipc", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path),
+                       env=dict(os.environ, FS_IPC_TIMEOUT_S="60", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("repeat")]
+    assert r.returncode == 0 and len(lines) == 2, (r.stdout[-1500:], r.stderr[-1500:])
+    for l in lines:
+        assert " True " in l and "'3': 3" in l, l
