@@ -110,7 +110,9 @@ int fs_destroy(fs_sim* s);
  *   "two_sweep_kernel" "auto" (default: timed once per grid) | "pair" | "fused" -- which of the two
  *                 two-sweep kernels (jacobi_pair_kernel / jacobi_fused_kernel<NL=2>) runs those passes;
  *   "advect_kernels" "cell" (default: one thread per cell) | "celltab" (the same reading clamped traces from the
- *                 column tables) | "row" (four cells per lane, clamp tables); all bit-identical, none faster by > 5 %;
+ *                 column tables) | "tile" (the tables' window around an 8 x 8 tile of rows staged in LDS, "advect_window"
+ *                 rows / planes wide) | "row" (four cells per lane, clamp tables); all bit-identical, none faster on the
+ *                 benchmark flow;
  *   "mg_cycles" (default 4: 75 % of the time of the 80 sweeps of config 3, residual 34x smaller), "mg_pre", "mg_post" (smoothing steps before / after the coarse correction, default 1),
  *                 "mg_coarse_iters" (iterations on the coarsest level, default 30): solver "mg" only;
  *   "launch_plans" "<two-sweep plan id>,<three-sweep plan id>" (what fs_get_int "pair_shape" / "triple_plan" reported
