@@ -57,8 +57,8 @@ struct SweepTune {
                               // cells per lane + clamp tables); bit-identical, within 5 % of each other (profiles/r03e_*, r02g_*)
     int advect_window = 24;   // advect_cell == 3 (the tile kernels): rows / planes around a tile whose inlet-table values are staged in
                               // LDS; a trace that ends further away takes the per-cell path (capped by what 64 KB of LDS hold)
-    int wall_free = 1;        // three-sweep kernel, whole-domain aligned grids: workgroups that touch no y / z wall run a wall-free
-                              // second body -- 0 never, 1 (default) when a launch has more than 256 workgroups, 2 always
+    int wall_free = 1;        // three-sweep kernel, whole-domain aligned grids: plane iterations that touch no y / z wall run a wall-free
+                              // second body -- 0 never, 1 (default) and 2 always (round 3: selected per group of three iterations)
     int two_kind = 0;         // which two-sweep kernel: 0 = timed choice, 1 = jacobi_pair_kernel only, 2 = jacobi_fused_kernel<NL=2> only
 };
 

@@ -88,7 +88,10 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wx = wave % NXW, wy = wave / NXW;
     const int W = g.W, H = g.H, D = g.D;
-    const int s = band * (BY - 2 * OV);                  // tile row t <-> grid row s + t
+    // tile row t <-> grid row s + t.  Band k outputs the BY - 2 OV rows k (BY - 2 OV) + 1 ..: every band the same number,
+    // also the bands at the y walls (a wall costs no rows, so with s = k (BY - 2 OV) the first band would output NL - 2 more
+    // than the others; round 3 shifts the origin instead, which makes the wall bands the lighter ones)
+    const int s = band * (BY - 2 * OV) - (OV - 1);
     const int ty0 = wy * RY, y0 = s + ty0;
     const int xl = wx * 256 + lane * 4;
     const int x0 = 1 + xl;
@@ -110,11 +113,19 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     // (interior bands x interior z chunks), in which every wall test, ghost row / ghost plane and the registers that carry
     // them are compiled out -- 523 instead of 837 instructions per plane, 126 instead of 152 VGPRs on its own.  The two are
     // separate loops selected once per workgroup (two bodies inside ONE loop spill at their merge, round 1).
-    auto run = [&](auto wallc) {
+    // The march's state lives outside the bodies so that a workgroup can change body between plane iterations (round 3):
+    T L0[3][RY][4], L1[3][RY][4] = {}, L2[3][RY][4] = {};
+    T hb[4], ht[4], eL[RY], eR[RY], rcur[RY][4];
+    T gz1[RY][4] = {}, gz2[RY][4] = {};                 // ghost plane D+1 of levels 1 and 2 while it waits for its register slot
+    unsigned flc[RY], kl[3][RY] = {};                    // (not in idle load registers: a select on those would wait for the loads)
+    // `ngroups` groups of three plane iterations from z_from on with one of the bodies (the register slots rotate with period
+    // three: a group starts and ends with every plane in its home slot, so bodies can alternate between groups), then, with
+    // tail_to >= 0, the march's last one or two iterations up to tail_to
+    auto run = [&](auto wallc, int z_from, int ngroups, int tail_to) {
     constexpr bool WALLS = decltype(wallc)::value != 0;
     const bool lo_wall_c = WALLS && lo_wall, hi_wall_c = WALLS && hi_wall;      // the ghost-plane code of the physical z walls
     // rows a level can be computed for: one fewer per level at a band edge, none lost at a wall
-    const bool top_in_tile = WALLS && (s + BY - 1 >= H + 1), bottom_in_tile = WALLS && (s == 0);
+    const bool top_in_tile = WALLS && (s + BY - 1 >= H + 1), bottom_in_tile = WALLS && (s <= 0);
     const int r2lo = bottom_in_tile ? 1 : s + 1, r2hi = top_in_tile ? H : s + BY - 2;
     const int r3lo = bottom_in_tile ? 1 : s + 2, r3hi = top_in_tile ? H : s + BY - 3;
     const int kill_shift = (b == 0) ? 0 : 4;
@@ -141,11 +152,6 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[e] = q.e[e];
     };
-
-    T L0[3][RY][4], L1[3][RY][4] = {}, L2[3][RY][4] = {};
-    T hb[4], ht[4], eL[RY], eR[RY], rcur[RY][4];
-    T gz1[RY][4] = {}, gz2[RY][4] = {};                 // ghost plane D+1 of levels 1 and 2 while it waits for its register slot
-    unsigned flc[RY], kl[3][RY] = {};                    // (not in idle load registers: a select on those would wait for the loads)
 
     auto load_core = [&](int z, T (&out)[RY][4]) {
         const char* sp = plane_of(src, z);
@@ -422,26 +428,43 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
         __syncthreads();
     };
 
-    load_core(lo1 - 1, L0[0]);
-    load_core(lo1, L0[1]);
-    load_core(min(lo1 + 1, zmax0), L0[2]);
-    load_side(lo1);
-    const int zl_end = zend + OV;
-    int zl = lo1;
-    for (;;) {
+    if (z_from == lo1) {                                 // the march starts here: first loads
+        load_core(lo1 - 1, L0[0]);
+        load_core(lo1, L0[1]);
+        load_core(min(lo1 + 1, zmax0), L0[2]);
+        load_side(lo1);
+    }
+    int zl = z_from;
+    for (int k = 0; k < ngroups; ++k) {
         iter(IC<0>{}, zl);
-        if (++zl > zl_end) break;
-        iter(IC<1>{}, zl);
-        if (++zl > zl_end) break;
-        iter(IC<2>{}, zl);
-        if (++zl > zl_end) break;
+        iter(IC<1>{}, zl + 1);
+        iter(IC<2>{}, zl + 2);
+        zl += 3;
+    }
+    if (zl <= tail_to) {
+        iter(IC<0>{}, zl);
+        if (zl + 1 <= tail_to) iter(IC<1>{}, zl + 1);
     }
     };
-    // a workgroup needs the general body if one of its rows is a wall row or one of its level planes a wall plane
-    const bool interior = (s > 0) && (s + BY - 1 < H) && (!lo_wall || lo1 >= 2) && (!hi_wall || hi1 <= D - 1);
-    if constexpr (WALLSEL == 2) run(IC<0>{});
-    else if (WALLSEL == 1 && interior) run(IC<0>{});
-    else run(IC<1>{});
+    const int zl_end = zend + OV;                        // the march: iterations lo1 .. zl_end
+    const int total = zl_end - lo1 + 1, ngroups = total / 3;
+    if constexpr (WALLSEL == 1) {
+        // Two bodies.  A band at a y wall runs the general one throughout (and is the lighter band, see `s`).  Any other band
+        // needs it only where a level touches a physical z wall: the iterations up to NL (plane 1 as level 1 .. NL) and those
+        // from D on; the groups of three iterations that contain none of those run the wall-free body.
+        const bool ywall = (s <= 0) || (s + BY - 1 >= H + 1);
+        // groups [0, g0) general, [g0, g1) wall-free, [g1, ngroups) + tail general
+        int g0 = ngroups, g1 = ngroups;
+        if (!ywall) {
+            g0 = (lo_wall && lo1 <= NL) ? min(ngroups, (NL - lo1) / 3 + 1) : 0;
+            g1 = hi_wall ? max(g0, min(ngroups, (D - lo1) / 3)) : ngroups;     // group k covers lo1 + 3k .. lo1 + 3k + 2 < D
+        }
+        run(IC<1>{}, lo1, g0, -1);
+        run(IC<0>{}, lo1 + 3 * g0, g1 - g0, -1);
+        run(IC<1>{}, lo1 + 3 * g1, ngroups - g1, zl_end);
+    } else {
+        run(IC<WALLSEL == 2 ? 0 : 1>{}, lo1, ngroups, zl_end);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -450,9 +473,9 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
 template <int NL>
 static int fused_bands(int H, int BY)
 {
-    // band k outputs rows k(BY-2(NL-1)) + NL-1 .. k(BY-2(NL-1)) + BY-NL (band 0 from row 1, the last band up to row H)
-    const int ov = NL - 1, first = BY - NL, step = BY - 2 * ov;
-    return (H <= first) ? 1 : (H - first + step - 1) / step + 1;
+    // band k outputs rows k (BY - 2 (NL-1)) + 1 .. (k + 1)(BY - 2 (NL-1)), the last band up to row H
+    const int step = BY - 2 * (NL - 1);
+    return (H + step - 1) / step;
 }
 
 template <class T, int NL, int NXW, int NYW, int RY>
@@ -508,10 +531,12 @@ static void launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc
     hipLaunchKernelGGL((jacobi_fused_kernel<T, NL, NXW, NYW, RY, AL, SL, WS>), dim3(nblk), dim3(THREADS), 0, st, g, sc, src, \
                        rhs, dst, flags, b, a, inv_c, z_first, z_last, zc_len, z_stride, nbands, nblk, pp)
     // The wall-free second body exists for the three-sweep kernel on lane-aligned whole-domain grids (the benchmark grids).
-    // It is 9 % (512^3) to 14 % (256^3) faster per workgroup, but a pass ends with its slowest workgroup: it only pays when a
-    // CU works through several workgroups (256^3: -2.5 %); with one workgroup per CU (512^3: 256 workgroups) the general
-    // ones set the time and the larger kernel costs 1 % (profiles/r03c_*, r03d_*).  "auto" therefore asks for > 256 workgroups.
-    const bool two_bodies = tune.wall_free == 2 || (tune.wall_free == 1 && nblk > 256);
+    // Rounds 1-2 selected a body per WORKGROUP: 9 % (512^3) to 14 % (256^3) faster for the interior ones, but a pass ends with its
+    // slowest workgroup, and at 512^3 (256 workgroups, one per CU) half of them touch a z wall.  Round 3 selects per GROUP OF
+    // THREE PLANE ITERATIONS instead (only the first and last groups of a z-wall chunk run the general body) and shifts the band
+    // origin so that the two y-wall bands, which run it throughout, carry one row less per level: 0.1448 -> 0.1371 ms per sweep
+    // at 512^3, 0.0172 -> 0.0166 at 256^3 (profiles/r3y_*), so "auto" now means always.
+    const bool two_bodies = tune.wall_free >= 1;
     if (aligned && whole && NL == 3 && two_bodies) FS_LAUNCH(true, false, 1);
     else if (aligned && whole) FS_LAUNCH(true, false, 0);
     else if (aligned) FS_LAUNCH(true, true, 0);
