@@ -178,6 +178,9 @@ __global__ __launch_bounds__(NXW* NYW * 64) void jacobi_fused_kernel(GridDesc g,
     };
 
     // one stencil application; simulation.cpp:264-269 order x+1, x-1, y+1, y-1, z+1, z-1
+    // (Writing the four cells as two interleaved packed chains removes 55 of the 73 hazard s_nops per plane iteration of
+    // the wall-free body and gains nothing -- 0.1301 against 0.1282 ms per sweep, round 3: the other waves of the SIMD fill
+    // those slots.)
     auto relax4 = [&](const T (&cc)[4], T left, T right, const T (&ym)[4], const T (&yp)[4], const T (&zm)[4],
                       const T (&zp)[4], const T (&rh)[4], T (&u)[4]) {
 #pragma unroll
@@ -535,7 +538,8 @@ static void launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc
     // slowest workgroup, and at 512^3 (256 workgroups, one per CU) half of them touch a z wall.  Round 3 selects per GROUP OF
     // THREE PLANE ITERATIONS instead (only the first and last groups of a z-wall chunk run the general body) and shifts the band
     // origin so that the two y-wall bands, which run it throughout, carry one row less per level: 0.1448 -> 0.1371 ms per sweep
-    // at 512^3, 0.0172 -> 0.0166 at 256^3 (profiles/r3y_*), so "auto" now means always.
+    // at 512^3 on one box, 0.1380 -> 0.1282 on another, 0.0172 -> 0.0166 at 256^3 (profiles/r3y_*); letting the y-wall bands
+    // run the wall-free body too (timing only) changes nothing any more, so "auto" now means always.
     const bool two_bodies = tune.wall_free >= 1;
     if (aligned && whole && NL == 3 && two_bodies) FS_LAUNCH(true, false, 1);
     else if (aligned && whole) FS_LAUNCH(true, false, 0);
