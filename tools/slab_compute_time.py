@@ -69,7 +69,7 @@ for overlap in ("1", "2", "0", "3", "auto"):
                                        "note": "%d ranks share ONE GPU" % P, "per_rank": res}
     else:
         out["rank"] = rank
-        r = one_rank(b"FSNULL:".ljust(128, b"\0"), overlap)
+        r = one_rank((b"FSNULL:push" if overlap == "3" else b"FSNULL:").ljust(128, b"\0"), overlap)   # 3: the push kernels, storing into the rank's own halos
         r["cells_steps_per_sec_if_all_ranks_alike"] = W * H * D / (r["ms_per_step"] * 1e-3)
         out["overlap=%s" % overlap] = r
     if P == 1:
