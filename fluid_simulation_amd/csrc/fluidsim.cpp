@@ -100,7 +100,10 @@ struct fs_sim {
     float omega = 1.0f;          // relaxation factor of solver=rbsor
     int plan_two = -2, plan_three = -2;   // "launch_plans": replay these instead of timing (-2: not set)
     int mg_cycles = 4, mg_pre = 1, mg_post = 1, mg_coarse = 30;   // solver=mg: V-cycles per pressure solve, smoothing steps, coarsest-level iterations
-    int mg_min_planes = 4;       // z-slabs: a coarse level stays distributed while every rank keeps at least this many of its planes
+    int mg_min_planes = 32;      // z-slabs: a coarse level stays distributed while every rank keeps at least this many of its planes
+                                 // (measured, 512^3 as four slabs: 4 -> 203, 16 -> 186, 32 -> 175, 64 -> 152 ms per step; below 32 the
+                                 // exchanges of a level cost more than computing it whole on every rank, above it the whole-held level
+                                 // of an 8-way split is as large as a rank's own slab)
     std::string dump_dir = "data";
     int dump_every = 1;
     unsigned voxel_seed = 1;

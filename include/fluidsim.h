@@ -60,7 +60,7 @@ enum {
                             * oracle/cpu_ref_mg.h); so does fs_linear_solver when called with that equation's coefficients
                             * (b = 0, a = 1, c = 6); every other solve (diffusion) runs Jacobi.  One GPU or z-slabs
                             * (a rank must then hold an even number of planes; option "mg_min_planes": coarse levels stay
-                            * distributed while every rank keeps that many planes, default 4, and are held whole by every
+                            * distributed while every rank keeps that many planes, default 32, and are held whole by every
                             * rank below); grids whose extents cannot be halved get no coarse levels.  SURVEY.md 8f rank 4 */
 };
 

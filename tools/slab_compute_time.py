@@ -30,7 +30,8 @@ FAMS = ("sweep", "sweep_pair", "sweep_triple", "divergence", "gradient", "advect
 
 def one_rank(uid, overlap):
     sim = F.Simulation(W, H, D, steps, acc=acc, quiet=1, dump_every=0, profile=1, overlap=overlap,
-                       solver=os.environ.get("FS_SOLVER", "jacobi"))      # FS_SOLVER=mg: the multigrid pressure solve on slabs
+                       solver=os.environ.get("FS_SOLVER", "jacobi"),      # FS_SOLVER=mg: the multigrid pressure solve on slabs
+                       mg_min_planes=int(os.environ.get("FS_MG_MIN_PLANES", "4")))
     if P > 1:
         sim.comm_init(rank, P, uid)
     sim.addObstacle(W // 3, H // 2, D // 2)              # every rank issues the same call (rank-symmetric bookkeeping)
