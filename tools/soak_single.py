@@ -16,9 +16,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for i in range(n):
-    W = int(rng.choice([rng.integers(1, 70), rng.integers(250, 262), rng.integers(505, 520), rng.integers(760, 775), rng.integers(1015, 1030)],
-                       p=[0.45, 0.2, 0.2, 0.05, 0.1]))
-    H, D = int(rng.integers(1, 36)), int(rng.integers(1, 28))
+    # (256 and 512 exactly: the lane-aligned builds of the three-sweep kernel with its two bodies per group of iterations)
+    W = int(rng.choice([rng.integers(1, 70), rng.integers(250, 262), rng.integers(505, 520), rng.integers(760, 775), rng.integers(1015, 1030), 256, 512],
+                       p=[0.3, 0.1, 0.1, 0.05, 0.1, 0.15, 0.2]))
+    H, D = (int(rng.integers(1, 70)), int(rng.integers(1, 60))) if W in (256, 512) else (int(rng.integers(1, 36)), int(rng.integers(1, 28)))
     acc, steps = int(rng.integers(0, 10)), int(rng.integers(1, 3))
     fp64 = bool(rng.random() < 0.35)
     opts = {"sweep_fuse": str(rng.choice([2, 3, 4, 4])), "two_sweep_kernel": str(rng.choice(["auto", "pair", "fused"])),
