@@ -541,8 +541,14 @@ static void launch_fused_v(hipStream_t st, const SweepTune& tune, const GridDesc
     // at 512^3 on one box, 0.1380 -> 0.1282 on another, 0.0172 -> 0.0166 at 256^3 (profiles/r3y_*); letting the y-wall bands
     // run the wall-free body too (timing only) changes nothing any more, so "auto" now means always.
     const bool two_bodies = tune.wall_free >= 1;
-    if (aligned && whole && NL == 3 && two_bodies) FS_LAUNCH(true, false, 1);
-    else if (aligned && whole) FS_LAUNCH(true, false, 0);
+    if constexpr (NL == 3) {                             // (the two-body builds exist for three sweeps only)
+        if (aligned && two_bodies) {
+            if (whole) FS_LAUNCH(true, false, 1);
+            else FS_LAUNCH(true, true, 1);               // z-slabs: an inner rank has no z wall at all
+            return;
+        }
+    }
+    if (aligned && whole) FS_LAUNCH(true, false, 0);
     else if (aligned) FS_LAUNCH(true, true, 0);
     else FS_LAUNCH(false, true, 0);
 #undef FS_LAUNCH

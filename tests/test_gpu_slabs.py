@@ -132,13 +132,16 @@ def test_slabs_match_single_gpu_bit_exact(tmp_path, nranks, D, opts, transport, 
                           # two-sweep kernel, fp64, three sweeps on 512-cell rows, and rbsor (its passes fall back to copies)
                           (1000, 8, 24, 2, "fp32", "jacobi", "overlap=3,two_sweep_kernel=pair"), (520, 7, 36, 3, "fp32", "jacobi", "overlap=3,two_sweep_kernel=fused"),
                           (300, 9, 32, 2, "fp64", "jacobi", "overlap=3"), (512, 8, 32, 2, "fp32", "jacobi", "overlap=3"),
-                          (24, 11, 32, 2, "fp32", "rbsor", "overlap=3")])
+                          (24, 11, 32, 2, "fp32", "rbsor", "overlap=3"),
+                          # lane-aligned rows on slabs: the three-sweep kernel with two bodies per group of iterations (an inner
+                          # rank has no z wall: wall-free body throughout; the outer ranks one each), all schedules' kernels
+                          (256, 30, 48, 3, "fp32", "jacobi", ""), (512, 20, 64, 4, "fp32", "jacobi", "overlap=3"), (256, 9, 32, 2, "fp32", "jacobi", "overlap=1,wall_free=0")])
 def test_slabs_wide_rows_and_fp64(tmp_path, W, H, D, nranks, precision, solver, opts):
     """More than one 256-cell chunk per row, fp64 fields, each of the solver kernels on a slab (fp32 rows up to
     512 cells: three sweeps per pass across three-deep halos; the fused and the pair two-sweep kernel), and the
     optional red-black SOR solver (cell colour follows the global z, so slabs must agree with one GPU)."""
-    args = [W, H, D, 7 if opts or W == 512 else 4, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision, solver, opts]
-    transport = "ipc" if "overlap=3" in opts else "shm"
+    args = [W, H, D, 7 if opts or W in (256, 512) else 4, 2, os.path.join(GOLDEN, "plate_ascii.stl"), precision, solver, opts]
+    transport = "ipc" if ("overlap=3" in opts or W == 256) else "shm"
     if transport == "ipc":
         ok, why = ipc_usable()
         if not ok:
