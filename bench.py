@@ -383,6 +383,10 @@ def main():
                                                   else "device-to-device copies between rank processes (FSIPC)")) if world > 1 else "single GPU",
             "voxelizer_points_added": added,
             "halo_transport": sim.comm_transport(),
+            # N > 1 lines run config 4 strong-scaled; the N = 1 line runs config 3 (the roofline run) and carries the matching
+            # single-GPU number of config 4 as extra_c4_single_gpu: divide by THAT for a scaling factor
+            "strong_scaling_base": ("extra_c4_single_gpu.cells_steps_per_sec of the --gpus 1 line (config 4 on one GPU)"
+                                    if world > 1 else None),
         },
         "jacobi_iter_per_sec": iters_per_sec,
         "roofline": {
