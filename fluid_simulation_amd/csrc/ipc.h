@@ -43,7 +43,7 @@ struct IpcSyncArgs {
 };
 
 // One wave.  Stores first (so that two ranks that wait for each other both get what they wait for), then waits.
-__global__ void ipc_sync_kernel(IpcSyncArgs a)
+static __global__ void ipc_sync_kernel(IpcSyncArgs a)
 {
     const int l = threadIdx.x;
     if (l < a.nstore) __hip_atomic_store(a.store[l], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -71,7 +71,7 @@ struct IpcReduceArgs {
     double* d3;                  // device: {sum, min, max} in, reduced over the ranks out (rank order, every rank the same bits)
 };
 
-__global__ void ipc_reduce_kernel(IpcReduceArgs a)
+static __global__ void ipc_reduce_kernel(IpcReduceArgs a)
 {
     const int l = threadIdx.x;
     if (l < 3) __hip_atomic_store(a.mine + l, a.d3[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
