@@ -240,6 +240,9 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); the solver has no CPU path")
+    if args.transport == "rccl" and torch.cuda.device_count() < world:
+        sys.exit("bench.py --gpus %d over RCCL needs %d GPUs (one per rank; %d visible): RCCL refuses ranks that share a device.  "
+                 "--transport ipc rehearses the N > 1 path with ranks sharing GPUs (never a result)" % (world, world, torch.cuda.device_count()))
     rehearsal = args.transport == "shm" or (args.transport == "ipc" and torch.cuda.device_count() < world)
     if rehearsal:
         local_rank = local_rank % torch.cuda.device_count()
