@@ -405,6 +405,11 @@ def test_bench_line_contract(tmp_path):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 1000.0
+    # the fraction that cannot exceed 1 is there (null without a PMC measurement of this very build and launch plan), and so
+    # is the floor of the traffic; one GPU: nothing scales
+    assert "frac_physical" in r and (r["frac_physical"] is None or 0.0 < r["frac_physical"] < 1.0)
+    assert (r["frac_physical"] is None) == (r["traffic"] is None)
+    assert r["min_traffic_bytes"] == 12 * 256 ** 3 and d["scaling"] is None and d["comm"] is None
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "64x64x64" in c["sample"]
 
