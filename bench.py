@@ -226,7 +226,9 @@ def main():
                          "staged synchronous development transport; never a result")
     ap.add_argument("--overlap", default="auto", choices=["auto", "0", "1", "2", "3"],
                     help="communication schedule of the slab passes (fs_set_option \"overlap\"); auto = timed over the real transport")
-    ap.add_argument("--comm-cus", default="0", help="CUs kept free of solver workgroups for the transport: 0 (default), N, or auto")
+    ap.add_argument("--comm-cus", default="auto",
+                    help="CUs kept free of solver workgroups for the transport's kernels: auto (default: none and 8 are both timed with "
+                         "the schedules, the slowest rank's time decides), 0, or N")
     args = ap.parse_args()
 
     import torch
